@@ -1,0 +1,153 @@
+"""Golden-fixture generator  --  TEST INFRASTRUCTURE, runs in the BUILD CONTAINER only.
+
+Imports the real implementation of the path (transformers 5.15.0
+VideoMAEForPreTraining, built from a config object exactly as
+pretraining/generative/pretrain_videomae.py:51-64 does, and the reference's own
+pretraining/generative/mask.py), loads the oracle's deterministic weights into
+it, runs forward+backward on the oracle's synthetic batches and writes small
+JSON fixtures under tests/golden/.  Nothing of the reference or of transformers
+is copied: the fixtures hold inputs' checksums and output numbers only.
+
+    python oracle/make_golden.py            # writes tests/golden/*.json
+
+It also asserts, while generating, that oracle/videomae_oracle.py agrees with
+the real implementation to fp32 round-off (this is what "pins" the oracle).
+"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+from oracle import videomae_oracle as vo  # noqa: E402
+
+REF = "/root/reference"
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def hf_model(cfg: vo.OracleConfig, params):
+    import transformers
+    hc = transformers.VideoMAEConfig(
+        image_size=cfg.image_size, patch_size=cfg.patch_size, num_channels=cfg.num_channels,
+        num_frames=cfg.num_frames, tubelet_size=cfg.tubelet_size, hidden_size=cfg.hidden_size,
+        num_hidden_layers=cfg.num_hidden_layers, num_attention_heads=cfg.num_attention_heads,
+        intermediate_size=cfg.intermediate_size, initializer_range=0.02, use_mean_pooling=True,
+        decoder_num_attention_heads=cfg.decoder_num_attention_heads,
+        decoder_hidden_size=cfg.decoder_hidden_size,
+        decoder_num_hidden_layers=cfg.decoder_num_hidden_layers,
+        decoder_intermediate_size=cfg.decoder_intermediate_size, norm_pix_loss=cfg.norm_pix_loss)
+    m = transformers.VideoMAEForPreTraining(hc)
+    assert list(m.state_dict().keys()) == list(params.keys()), "state-dict key order drifted"
+    m.load_state_dict(params)
+    m.train()
+    return m, transformers.__version__
+
+
+def summarize(t: torch.Tensor, n=8):
+    t = t.detach().double().flatten()
+    return {"l2": float(t.norm()), "mean": float(t.mean()), "head": [float(x) for x in t[:n]],
+            "numel": int(t.numel())}
+
+
+def hf_taps(model, pixels, mask):
+    """Run HF with forward hooks that record the same activations the oracle taps."""
+    taps = {}
+    hooks = []
+
+    def add(mod, name, pick=lambda o: o):
+        hooks.append(mod.register_forward_hook(lambda m, i, o: taps.__setitem__(name, pick(o))))
+
+    add(model.videomae.embeddings, "embed")
+    for i, l in enumerate(model.videomae.encoder.layer):
+        add(l, f"enc{i}")
+    for i, l in enumerate(model.decoder.decoder_layers):
+        add(l, f"dec{i}")
+    hooks.append(model.decoder.register_forward_pre_hook(lambda m, a: taps.__setitem__("x_full", a[0])))
+    out = model(pixels, bool_masked_pos=mask)
+    for h in hooks:
+        h.remove()
+    taps["logits"] = out.logits
+    return out, taps
+
+
+def one_case(name, cfg, batch, seed, mask_ratio, wseed=0):
+    params = vo.make_params(cfg, seed=wseed)
+    pixels, mask = vo.synthetic_batch(cfg, batch, seed, mask_ratio)
+    model, ver = hf_model(cfg, params)
+    out, htaps = hf_taps(model, pixels, mask)
+    out.loss.backward()
+    hgrads = {k: v.grad for k, v in model.named_parameters()}
+
+    otaps = {}
+    oloss, ograds = vo.step(cfg, params, pixels, mask, taps=otaps)
+
+    # ---- pin the oracle against the real implementation
+    rel = abs(float(oloss) - float(out.loss)) / abs(float(out.loss))
+    assert rel < 2e-6, (name, "loss", rel)
+    for k, v in htaps.items():
+        e = float((otaps[k] - v).norm() / v.norm())
+        assert e < 2e-5, (name, "tap", k, e)
+    worst = 0.0
+    gmax = max(float(g.norm()) for g in hgrads.values())
+    for k, g in hgrads.items():
+        # key.bias has a mathematically zero gradient (softmax is shift invariant along
+        # keys), so the error is measured against ||g|| plus a floor tied to the largest grad.
+        e = float((ograds[k] - g).norm() / (g.norm() + 1e-4 * gmax))
+        worst = max(worst, e)
+        assert e < 5e-5, (name, "grad", k, e)
+    print(f"[{name}] oracle vs transformers {ver}: loss rel {rel:.2e}, worst grad rel {worst:.2e}")
+
+    fx = {
+        "case": name, "transformers": ver, "torch": torch.__version__,
+        "config": cfg.__dict__, "batch": batch, "seed": seed, "weight_seed": wseed, "mask_ratio": mask_ratio,
+        "input": {"pixels": summarize(pixels), "mask_true": int(mask.sum()),
+                  "visible_idx_row0": [int(i) for i in torch.nonzero(~mask[0]).flatten()[:32]]},
+        "loss": float(out.loss),
+        "taps": {k: summarize(v) for k, v in htaps.items()},
+        "grad_l2": {k: float(g.double().norm()) for k, g in hgrads.items()},
+        "grad_head": {k: [float(x) for x in hgrads[k].flatten()[:4]] for k in vo.GRAD_PROBES},
+        "grad_probes": {k: float(hgrads[k].double().norm()) for k in vo.GRAD_PROBES},
+    }
+    with open(os.path.join(GOLD, f"videomae_{name}.json"), "w") as f:
+        json.dump(fx, f, indent=1)
+
+
+def mask_fixture():
+    """pretraining/generative/mask.py under a fixed numpy seed (the reference never seeds numpy)."""
+    sys.path.insert(0, os.path.join(REF, "pretraining", "generative"))
+    import mask as refmask  # reference module: numpy only
+    cases = []
+    for seed, grid, ratio in [(0, (8, 14, 14), 0.9), (7, (8, 14, 14), 0.9), (3, (2, 4, 4), 0.75)]:
+        np.random.seed(seed)
+        gen = refmask.TubeMaskingGenerator(grid, ratio)
+        rows = [gen() for _ in range(3)]
+        mine_rng = np.random.RandomState(seed)
+        for r in rows:
+            assert np.array_equal(r, vo.tube_mask(grid, ratio, mine_rng))
+        cases.append({"seed": seed, "grid": list(grid), "ratio": ratio,
+                      "num_masks_per_frame": int(gen.num_masks_per_frame),
+                      "total_masks": int(gen.total_masks),
+                      "visible_frame0": [[int(i) for i in np.nonzero(r[:grid[1] * grid[2]] == 0)[0]] for r in rows]})
+    with open(os.path.join(GOLD, "tube_mask.json"), "w") as f:
+        json.dump({"source": "pretraining/generative/mask.py:3-24", "cases": cases}, f, indent=1)
+    print("[mask] reference TubeMaskingGenerator == oracle.tube_mask for", len(cases), "cases")
+
+
+def main():
+    os.makedirs(GOLD, exist_ok=True)
+    torch.manual_seed(0)
+    mask_fixture()
+    one_case("tiny_s0", vo.TINY, batch=2, seed=0, mask_ratio=0.75)
+    one_case("tiny_s1", vo.TINY, batch=3, seed=1, mask_ratio=0.75, wseed=1)
+    one_case("base_b2_s0", vo.BASE, batch=2, seed=0, mask_ratio=0.9)
+    one_case("base_b2_s1", vo.BASE, batch=2, seed=1, mask_ratio=0.9, wseed=1)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,99 @@
+"""ctypes binding of libbvc_hip.so (C ABI declared in include/bvc.h).
+
+There is no CPU fallback: if the shared library is missing or a call fails, an exception is raised.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libbvc_hip.so")
+
+c_void_p, c_int, c_int64, c_float, c_char_p = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_char_p
+
+
+class BvcError(RuntimeError):
+    pass
+
+
+class VideoMAEConfigC(ctypes.Structure):
+    _fields_ = [(n, c_int) for n in (
+        "image_size", "patch_size", "num_channels", "num_frames", "tubelet_size",
+        "hidden_size", "num_hidden_layers", "num_attention_heads", "intermediate_size",
+        "decoder_hidden_size", "decoder_num_hidden_layers", "decoder_num_attention_heads",
+        "decoder_intermediate_size")] + [("layer_norm_eps", c_float), ("decoder_norm_eps", c_float),
+                                         ("norm_pix_loss", c_int)]
+
+
+class GemmDesc(ctypes.Structure):
+    _fields_ = [
+        ("A", c_void_p), ("B", c_void_p),
+        ("M", c_int), ("N", c_int), ("K", c_int), ("lda", c_int), ("ldb", c_int),
+        ("a_bytes", ctypes.c_uint32), ("b_bytes", ctypes.c_uint32),
+        ("alpha", c_float), ("alpha_dev", c_void_p),
+        ("epi", c_int), ("split_k", c_int),
+        ("C", c_void_p), ("ldc", c_int), ("C2", c_void_p),
+        ("bias", c_void_p), ("resid", c_void_p), ("aux", c_void_p), ("ldaux", c_int),
+        ("rowtok", c_void_p), ("pos", c_void_p), ("labels", c_void_p), ("partial", c_void_p),
+        ("rin", c_int), ("rout", c_int),
+    ]
+
+
+BUCKET_FN = ctypes.CFUNCTYPE(None, c_int64, c_int64, c_void_p)
+
+# every symbol include/bvc.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "bvc_last_error": (c_char_p, []),
+    "bvc_version": (c_char_p, []),
+    "bvc_videomae_param_count": (c_int, [ctypes.POINTER(VideoMAEConfigC)]),
+    "bvc_videomae_param_numel": (c_int64, [ctypes.POINTER(VideoMAEConfigC)]),
+    "bvc_videomae_param_info": (c_int, [ctypes.POINTER(VideoMAEConfigC), c_int, ctypes.c_char_p, c_int,
+                                        ctypes.POINTER(c_int64), ctypes.POINTER(c_int64), ctypes.POINTER(c_int),
+                                        ctypes.POINTER(c_int64)]),
+    "bvc_videomae_create": (c_int, [ctypes.POINTER(VideoMAEConfigC), c_int, c_int, ctypes.POINTER(c_void_p)]),
+    "bvc_videomae_destroy": (None, [c_void_p]),
+    "bvc_videomae_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "bvc_videomae_backward": (c_int, [c_void_p, c_void_p, c_void_p, BUCKET_FN, c_void_p, c_void_p]),
+    "bvc_videomae_tap": (c_int, [c_void_p, c_char_p, c_void_p, c_int64, ctypes.POINTER(c_int64), c_void_p]),
+    "bvc_op_gemm": (c_int, [ctypes.POINTER(GemmDesc), c_int, c_int, c_int, c_void_p]),
+    "bvc_op_gemm_num_tiles": (c_int, [ctypes.POINTER(GemmDesc), c_int]),
+    "bvc_op_attention_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "bvc_op_attention_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "bvc_op_layernorm_fwd": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                     c_int, c_int, c_float, c_void_p]),
+    "bvc_op_layernorm_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                     c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "bvc_op_colsum_bf16": (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
+    "bvc_op_cast_bf16": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "bvc_op_mask_index": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "bvc_op_gather_patches": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "bvc_op_pixel_labels": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load libbvc_hip.so once; raise loudly if it has not been built (no fallback path exists)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise BvcError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)   # AttributeError if the library does not export a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().bvc_last_error()
+        raise BvcError(f"{what} failed with status {rc}: {msg.decode() if msg else ''}")
+
+
+def current_stream_ptr():
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)

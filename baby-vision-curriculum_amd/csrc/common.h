@@ -1,0 +1,67 @@
+// Shared device/host helpers for libbvc_hip.so (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint16_t bf16_t;  // raw bfloat16 bits
+typedef __attribute__((ext_vector_type(8))) short bf16x8;   // 8 bf16 = one MFMA A/B fragment (4 VGPRs)
+typedef __attribute__((ext_vector_type(4))) short bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+// round-to-nearest-even; the plain cast lowers to v_cvt_pk_bf16_f32 on gfx950 and keeps NaN a NaN
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    __bf16 b = (__bf16)f;
+    return *reinterpret_cast<bf16_t*>(&b);
+}
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
+    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// exact-erf GELU (the reference's hidden_act="gelu", HF:299-308) and its derivative
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float dgelu_f(float x) {
+    return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.39894228040143268f * __expf(-0.5f * x * x);
+}
+
+// buffer resource over [base, base+bytes): out-of-range lanes of a buffer load return 0
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
+}
+
+// ---------------------------------------------------------------- host side
+#include <string>
+namespace bvc {
+void set_error(const char* fmt, ...);
+const char* last_error();
+}
+#include "../../include/bvc.h"
+#define BVC_CHECK_HIP(expr)                                                              \
+    do {                                                                                 \
+        hipError_t _e = (expr);                                                          \
+        if (_e != hipSuccess) {                                                          \
+            bvc::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return BVC_ERR_HIP;                                                          \
+        }                                                                                \
+    } while (0)
+#define BVC_REQUIRE(cond, ...)                 \
+    do {                                       \
+        if (!(cond)) {                         \
+            bvc::set_error(__VA_ARGS__);       \
+            return BVC_ERR_INVALID;            \
+        }                                      \
+    } while (0)

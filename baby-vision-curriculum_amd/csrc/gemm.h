@@ -1,0 +1,40 @@
+// bf16 MFMA GEMM for gfx950: problem descriptors and launcher (internal to libbvc_hip.so).
+#pragma once
+#include "common.h"
+#include "../../include/bvc.h"
+
+namespace bvc {
+
+// C[M,N] = epilogue(alpha * sum_k A(m,k) * B(k,n))
+// Operand storage ("layout"):
+//   GEMM_NT : A stored [M][lda] (k contiguous), B stored [N][ldb] (k contiguous)   y = x W^T   (forward Linear)
+//   GEMM_NN : A stored [M][lda] (k contiguous), B stored [K][ldb] (n contiguous)   dx = dy W   (input gradient)
+//   GEMM_TN : A stored [K][lda] (m contiguous), B stored [K][ldb] (n contiguous)   dW = dy^T x (weight gradient)
+enum GemmLayout { GEMM_NT = BVC_GEMM_NT, GEMM_NN = BVC_GEMM_NN, GEMM_TN = BVC_GEMM_TN };
+
+enum GemmEpilogue {
+    EPI_F32 = BVC_EPI_F32,          // C f32 = v (+bias)            ; split_k>1: atomicAdd into C (C pre-zeroed / accumulating)
+    EPI_BF16 = BVC_EPI_BF16,        // C bf16 = v (+bias)
+    EPI_GELU = BVC_EPI_GELU,        // C bf16 = v+bias (pre-activation), C2 bf16 = gelu(v+bias)
+    EPI_RESID = BVC_EPI_RESID,      // C f32 = resid + v + bias      (resid may alias C); split_k>1: atomicAdd, resid must alias C
+    EPI_POS = BVC_EPI_POS,          // C f32 = v + bias + pos[rowtok[m]][n]
+    EPI_E2D = BVC_EPI_E2D,          // C f32[(m/rin)*rout + m%rin][n] = v + pos[rowtok[m]][n]
+    EPI_LOSS = BVC_EPI_LOSS,        // d = v + bias - labels[m][n]; C bf16 = d; C2 f32 = v+bias (optional); partial[tile] = sum d^2
+    EPI_DGELU = BVC_EPI_DGELU,      // C bf16 = v * gelu'(aux[m][n])
+    EPI_F32_BF16 = BVC_EPI_F32_BF16 // C f32 = v (+bias), C2 bf16 = same value
+};
+
+// the public descriptor IS the internal problem record (include/bvc.h)
+using GemmProblem = bvc_gemm_desc;
+
+constexpr int kMaxGroup = 4;
+
+// Launch 1..4 independent problems of the same layout as ONE grid (grouped GEMM) on `stream`.
+// tile_cfg: -1 = pick from the tile count; 0 = 128x128, 1 = 128x64, 2 = 64x64.
+int launch_gemm(const GemmProblem* probs, int nprob, GemmLayout layout, int tile_cfg, hipStream_t stream);
+
+// number of loss partials an EPI_LOSS problem writes with the tile config launch_gemm would pick
+int gemm_num_tiles(const GemmProblem& p, int tile_cfg);
+int gemm_pick_tile(const GemmProblem* probs, int nprob, int tile_cfg);
+
+}  // namespace bvc

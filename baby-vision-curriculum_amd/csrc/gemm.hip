@@ -1,0 +1,332 @@
+// bf16 x bf16 -> f32 MFMA GEMM for gfx950 (MI355X), with the fused epilogues the ViT step needs.
+//
+// Structure (per 256-thread workgroup = 4 waves as 2x2, 64-deep K steps):
+//   * A and B tiles go HBM -> LDS directly with `buffer_load_dwordx4 ... lds` (LDS-DMA, 1 KiB per
+//     wave-instruction).  The buffer descriptor's bounds check returns zeros for rows past the end of
+//     the allocation, which is how ragged M / ragged contraction lengths are handled - no host padding.
+//   * two LDS stages; the DMA for K-step t+1 is issued right after the barrier that publishes step t,
+//     so it flies under step t's MFMAs (one barrier per K step).
+//   * LDS images are XOR-swizzled on the 16-byte chunk index.  LDS-DMA writes lane-linear, so the
+//     swizzle is applied to the per-lane SOURCE address and again on the read (both sides or neither).
+//   * k-contiguous operands are read with ds_read_b128; operands whose contraction index is the
+//     strided one (dX = dY W, dW = dY^T X) stay in their natural layout in HBM and LDS and are
+//     transposed on the LDS read by ds_read_b64_tr_b16 - no transposed copies of weights or activations.
+//   * v_mfma_f32_16x16x32_bf16 with the operands swapped, so each lane ends up with 4 consecutive
+//     output columns of one row: epilogue loads/stores are 8-16 B per lane.
+//   * block index -> tile mapping is XCD-aware (blocks b and b+8 share an XCD/L2): each XCD gets a
+//     contiguous run of tiles, consecutive tiles share the A row panel.
+//   * up to 4 independent problems per launch (grouped GEMM) to fill 256 CUs with the small
+//     weight-gradient products of one transformer layer.
+#include "gemm.h"
+
+namespace bvc {
+
+struct GemmGroup {
+    int nprob;
+    int tile_start[kMaxGroup + 1];
+    GemmProblem prob[kMaxGroup];
+};
+
+// ------------------------------------------------------------------ swizzles (16-byte chunk index)
+// k-contiguous image [rows][64] bf16, 128-B rows, read by ds_read_b128 (16 lanes = 16 rows, same chunk)
+__device__ __forceinline__ int swz_rows(int r) { return (r >> 1) & 7; }
+// transposed images [64 k][BR] bf16, read by ds_read_b64_tr_b16 (a 32-lane half = 8 k-rows x 32 B)
+template <int BR>
+__device__ __forceinline__ int swz_tr(int k) {
+    if constexpr (BR == 128) return ((k & 3) | (((k >> 3) & 1) << 2)) << 1;   // 256-B rows
+    else return (((k >> 1) & 1) | (((k >> 3) & 1) << 1)) << 1;                  // 128-B rows
+}
+
+// ------------------------------------------------------------------ HBM -> LDS staging of one operand tile
+// Non-transposed: rows r0..r0+BR-1 (output dim), k0..k0+63 of a [R][ld] array -> image [BR][64].
+// Transposed:     k rows k0..k0+63, columns r0..r0+BR-1 of a [Kc][ld] array    -> image [64][BR].
+template <int BR, bool T>
+__device__ __forceinline__ void stage_tile(__amdgpu_buffer_rsrc_t rs, int r0, int k0, int ld, char* lds,
+                                           int wave, int lane) {
+    constexpr int PIECES = BR * 64 * 2 / 1024;
+#pragma unroll
+    for (int jj = 0; jj < PIECES / 4; ++jj) {
+        const int j = wave + 4 * jj;   // wave-uniform piece index; piece j = LDS bytes [1024 j, 1024 j + 1024)
+        uint32_t off;
+        if constexpr (!T) {
+            const int r = 8 * j + (lane >> 3);
+            const int c = (lane & 7) ^ swz_rows(r);
+            off = (uint32_t)(((r0 + r) * ld + k0 + c * 8) * 2);
+        } else if constexpr (BR == 128) {
+            const int kr = 4 * j + (lane >> 4);
+            const int c = (lane & 15) ^ swz_tr<128>(kr);
+            off = (uint32_t)(((k0 + kr) * ld + r0 + c * 8) * 2);
+        } else {
+            const int kr = 8 * j + (lane >> 3);
+            const int c = (lane & 7) ^ swz_tr<64>(kr);
+            off = (uint32_t)(((k0 + kr) * ld + r0 + c * 8) * 2);
+        }
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(lds + j * 1024), 16, off, 0, 0, 0);
+    }
+}
+
+// ------------------------------------------------------------------ LDS -> MFMA fragment
+// Returns, for lane l, the 8 bf16  X[out = rbase + (l & 15)][k = 32 ks + 8 (l >> 4) + 0..7].
+template <int BR, bool T>
+__device__ __forceinline__ bf16x8 read_frag(const char* lds, int rbase, int ks, int lane) {
+    if constexpr (!T) {
+        const int r = rbase + (lane & 15);
+        const int c = 4 * ks + (lane >> 4);
+        return *reinterpret_cast<const __attribute__((address_space(3))) bf16x8*>(
+            (const __attribute__((address_space(3))) char*)(lds) + r * 128 + ((c ^ swz_rows(r)) << 4));
+    } else {
+        // lane 4q+p of each 16-lane group supplies the address of k-row q, columns 4p..4p+3;
+        // lane i of the group receives column i of the 4 k-rows (hardware transpose).
+        const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+        const int k0 = 32 * ks + 8 * g + q, k1 = k0 + 4;
+        const int chunk = (rbase >> 3) + (p >> 1);
+        const int within = (p & 1) * 8;
+        const char* a0 = lds + k0 * (BR * 2) + ((chunk ^ swz_tr<BR>(k0)) << 4) + within;
+        const char* a1 = lds + k1 * (BR * 2) + ((chunk ^ swz_tr<BR>(k1)) << 4) + within;
+        bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)(a0));
+        bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)(a1));
+        bf16x8 r;
+        r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+        r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+        return r;
+    }
+}
+
+// ------------------------------------------------------------------ the kernel
+template <int BM, int BN, bool AT, bool BT>
+__global__ __launch_bounds__(256) void gemm_kernel(const GemmGroup g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int BK = 64;
+    constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
+    constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 16, TN = WN / 16;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // XCD-aware remap (bijective for any grid size): XCD x owns a contiguous run of logical ids
+    const int nb = gridDim.x, bid = blockIdx.x;
+    const int xq = nb >> 3, xr = nb & 7, xcd = bid & 7;
+    int lid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
+
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < kMaxGroup; ++i)
+        if (i < g.nprob && lid >= g.tile_start[i]) pi = i;
+    const GemmProblem& p = g.prob[pi];
+    lid -= g.tile_start[pi];
+    const int split = lid % p.split_k;
+    const int tile = lid / p.split_k;
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+
+    const int nt_all = (p.K + BK - 1) / BK;
+    const int per = (nt_all + p.split_k - 1) / p.split_k;
+    const int t0 = split * per;
+    const int t1 = min(nt_all, t0 + per);
+    const int nt = t1 - t0;
+
+    const __amdgpu_buffer_rsrc_t ra = make_rsrc(p.A, p.a_bytes);
+    const __amdgpu_buffer_rsrc_t rb = make_rsrc(p.B, p.b_bytes);
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    if (nt > 0) {
+        stage_tile<BM, AT>(ra, m0, t0 * BK, p.lda, smem, wave, lane);
+        stage_tile<BN, BT>(rb, n0, t0 * BK, p.ldb, smem + A_BYTES, wave, lane);
+    }
+    for (int it = 0; it < nt; ++it) {
+        // every wave drains its own DMA, then the barrier publishes the whole tile; the same barrier
+        // proves all waves are done reading the other stage (they read it before arriving here)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (it + 1 < nt) {
+            char* nxt = smem + ((it + 1) & 1) * STAGE;
+            stage_tile<BM, AT>(ra, m0, (t0 + it + 1) * BK, p.lda, nxt, wave, lane);
+            stage_tile<BN, BT>(rb, n0, (t0 + it + 1) * BK, p.ldb, nxt + A_BYTES, wave, lane);
+        }
+        const char* la = smem + (it & 1) * STAGE;
+        const char* lb = la + A_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 af[TM], bfr[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = read_frag<BM, AT>(la, wm * WM + 16 * i, ks, lane);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bfr[j] = read_frag<BN, BT>(lb, wn * WN + 16 * j, ks, lane);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    // operands swapped: D = Bfrag^T-view x Afrag gives lane (l&15) = m, regs = 4 consecutive n
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    // ------------------------------------------------------------------ epilogue
+    const int epi = p.epi;
+    const float alpha = p.alpha_dev ? p.alpha * p.alpha_dev[0] : p.alpha;
+    float sumsq = 0.f;
+    const bool atomic = p.split_k > 1;
+    if (nt > 0 || !atomic) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = m0 + wm * WM + 16 * i + (lane & 15);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + wn * WN + 16 * j + 4 * (lane >> 4);
+                if (m >= p.M || n >= p.N) continue;
+                f32x4 v = acc[i][j] * alpha;
+                if (p.bias && (!atomic || split == 0)) {
+                    const f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + n);
+                    v += b;
+                }
+                const size_t idx = (size_t)m * p.ldc + n;
+                switch (epi) {
+                    case EPI_F32: {
+                        float* c = reinterpret_cast<float*>(p.C) + idx;
+                        if (atomic) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) atomicAdd(c + e, v[e]);
+                        } else {
+                            *reinterpret_cast<f32x4*>(c) = v;
+                        }
+                    } break;
+                    case EPI_BF16: {
+                        uint2 o = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+                        *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + idx) = o;
+                    } break;
+                    case EPI_GELU: {
+                        uint2 o = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+                        *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + idx) = o;
+                        uint2 a = {pack2bf(gelu_f(v[0]), gelu_f(v[1])), pack2bf(gelu_f(v[2]), gelu_f(v[3]))};
+                        *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C2) + idx) = a;
+                    } break;
+                    case EPI_RESID: {
+                        float* c = reinterpret_cast<float*>(p.C) + idx;
+                        if (atomic) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) atomicAdd(c + e, v[e]);
+                        } else {
+                            const f32x4 r = *reinterpret_cast<const f32x4*>(p.resid + idx);
+                            *reinterpret_cast<f32x4*>(c) = r + v;
+                        }
+                    } break;
+                    case EPI_POS: {
+                        const f32x4 pe = *reinterpret_cast<const f32x4*>(p.pos + (size_t)p.rowtok[m] * p.N + n);
+                        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + idx) = v + pe;
+                    } break;
+                    case EPI_E2D: {
+                        const f32x4 pe = *reinterpret_cast<const f32x4*>(p.pos + (size_t)p.rowtok[m] * p.N + n);
+                        const size_t orow = (size_t)(m / p.rin) * p.rout + (m % p.rin);
+                        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + orow * p.ldc + n) = v + pe;
+                    } break;
+                    case EPI_LOSS: {
+                        if (p.C2) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C2) + idx) = v;
+                        const f32x4 lab = *reinterpret_cast<const f32x4*>(p.labels + idx);
+                        const f32x4 d = v - lab;
+                        sumsq += d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3];
+                        uint2 o = {pack2bf(d[0], d[1]), pack2bf(d[2], d[3])};
+                        *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + idx) = o;
+                    } break;
+                    case EPI_DGELU: {
+                        const uint2 a = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(p.aux) + (size_t)m * p.ldaux + n);
+                        const float x0 = __uint_as_float(a.x << 16), x1 = __uint_as_float(a.x & 0xffff0000u);
+                        const float x2 = __uint_as_float(a.y << 16), x3 = __uint_as_float(a.y & 0xffff0000u);
+                        uint2 o = {pack2bf(v[0] * dgelu_f(x0), v[1] * dgelu_f(x1)),
+                                   pack2bf(v[2] * dgelu_f(x2), v[3] * dgelu_f(x3))};
+                        *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + idx) = o;
+                    } break;
+                    case EPI_F32_BF16: {
+                        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + idx) = v;
+                        uint2 o = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+                        *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C2) + idx) = o;
+                    } break;
+                    default: break;
+                }
+            }
+        }
+    }
+    if (epi == EPI_LOSS) {   // uniform per workgroup: deterministic per-tile partial of sum (logit-label)^2
+        float* red = reinterpret_cast<float*>(smem);
+        const float w = wave_sum(sumsq);
+        __syncthreads();
+        if (lane == 0) red[wave] = w;
+        __syncthreads();
+        if (tid == 0) p.partial[tile] = (red[0] + red[1]) + (red[2] + red[3]);
+    }
+}
+
+// ------------------------------------------------------------------ host side
+static void tile_dims(int cfg, int& bm, int& bn) {
+    bm = cfg == 2 ? 64 : 128;
+    bn = cfg == 0 ? 128 : 64;
+}
+
+static int tiles_for(const GemmProblem& p, int cfg) {
+    int bm, bn;
+    tile_dims(cfg, bm, bn);
+    return ((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn);
+}
+
+int gemm_pick_tile(const GemmProblem* probs, int nprob, int tile_cfg) {
+    if (tile_cfg >= 0) return tile_cfg;
+    // 256 CUs, 2+ workgroups per CU resident: prefer the big tile once it alone fills the chip
+    for (int cfg = 0; cfg < 2; ++cfg) {
+        int t = 0;
+        for (int i = 0; i < nprob; ++i) t += tiles_for(probs[i], cfg) * probs[i].split_k;
+        if (t >= (cfg == 0 ? 300 : 200)) return cfg;
+    }
+    return 2;
+}
+
+int gemm_num_tiles(const GemmProblem& p, int tile_cfg) { return tiles_for(p, gemm_pick_tile(&p, 1, tile_cfg)); }
+
+template <int BM, int BN>
+static int launch_cfg(const GemmGroup& g, GemmLayout layout, int nblocks, hipStream_t stream) {
+    const size_t lds = 2 * (BM + BN) * 64 * 2;
+    switch (layout) {
+        case GEMM_NT: hipLaunchKernelGGL((gemm_kernel<BM, BN, false, false>), dim3(nblocks), dim3(256), lds, stream, g); break;
+        case GEMM_NN: hipLaunchKernelGGL((gemm_kernel<BM, BN, false, true>), dim3(nblocks), dim3(256), lds, stream, g); break;
+        case GEMM_TN: hipLaunchKernelGGL((gemm_kernel<BM, BN, true, true>), dim3(nblocks), dim3(256), lds, stream, g); break;
+        default: set_error("launch_gemm: bad layout %d", (int)layout); return BVC_ERR_INVALID;
+    }
+    BVC_CHECK_HIP(hipGetLastError());
+    return BVC_OK;
+}
+
+int launch_gemm(const GemmProblem* probs, int nprob, GemmLayout layout, int tile_cfg, hipStream_t stream) {
+    BVC_REQUIRE(nprob >= 1 && nprob <= kMaxGroup, "launch_gemm: nprob %d out of range", nprob);
+    const int cfg = gemm_pick_tile(probs, nprob, tile_cfg);
+    GemmGroup g;
+    g.nprob = nprob;
+    int total = 0;
+    for (int i = 0; i < nprob; ++i) {
+        const GemmProblem& p = probs[i];
+        BVC_REQUIRE(p.M > 0 && p.N > 0 && p.K > 0, "launch_gemm: empty problem %d (%d,%d,%d)", i, p.M, p.N, p.K);
+        BVC_REQUIRE(p.N % 8 == 0, "launch_gemm: N=%d must be a multiple of 8", p.N);
+        BVC_REQUIRE(p.lda % 8 == 0 && p.ldb % 8 == 0 && p.ldc % 4 == 0, "launch_gemm: leading dims must be 16-byte aligned");
+        if (layout != GEMM_TN) BVC_REQUIRE(p.K % 64 == 0, "launch_gemm: K=%d must be a multiple of 64 for k-contiguous operands", p.K);
+        if (layout == GEMM_TN) BVC_REQUIRE(p.M % 8 == 0, "launch_gemm: TN needs M %% 8 == 0 (M=%d)", p.M);
+        BVC_REQUIRE(p.split_k >= 1, "launch_gemm: split_k must be >= 1");
+        if (p.split_k > 1)
+            BVC_REQUIRE(p.epi == EPI_F32 || (p.epi == EPI_RESID && p.resid == p.C),
+                        "launch_gemm: split_k needs an accumulating f32 epilogue");
+        g.prob[i] = p;
+        g.tile_start[i] = total;
+        total += tiles_for(p, cfg) * p.split_k;
+    }
+    g.tile_start[nprob] = total;
+    for (int i = nprob; i < kMaxGroup; ++i) { g.prob[i] = probs[0]; g.tile_start[i + 1] = total; }
+    switch (cfg) {
+        case 0: return launch_cfg<128, 128>(g, layout, total, stream);
+        case 1: return launch_cfg<128, 64>(g, layout, total, stream);
+        default: return launch_cfg<64, 64>(g, layout, total, stream);
+    }
+}
+
+}  // namespace bvc

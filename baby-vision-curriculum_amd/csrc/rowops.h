@@ -1,0 +1,31 @@
+// HBM-bound row / element kernels (internal to libbvc_hip.so).
+#pragma once
+#include "common.h"
+
+namespace bvc {
+
+// logical row m -> physical row (m / rin) * rout + roff + m % rin; rin <= 0 means identity.
+// Used to address "the last nmask tokens of every clip" without copying them out.
+struct RowMap { int rin, rout, roff; };
+static inline RowMap identity_rows() { return RowMap{0, 0, 0}; }
+
+// clip f32 [B][T][C][H][W]; tubes of ts frames x ps x ps pixels
+struct PatchGeom { int T, C, H, W, ts, ps; };
+
+int launch_ln_fwd(const float* x, RowMap rm, const float* gamma, const float* beta, bf16_t* y, float* mean, float* rstd,
+                  int M, int D, float eps, hipStream_t s);
+int launch_ln_bwd(const bf16_t* dy, const float* x, RowMap rm, const float* mean, const float* rstd, const float* gamma,
+                  float* dres, int accumulate, bf16_t* dres_bf, float* dgamma, float* dbeta, int M, int D, hipStream_t s);
+int launch_colsum_bf16(const bf16_t* X, int M, int N, int ld, float alpha, float* out, hipStream_t s);
+int launch_colsum_bf16_scaled(const bf16_t* X, int M, int N, int ld, float alpha, const float* alpha_dev, float* out, hipStream_t s);
+int launch_colsum_f32(const float* X, RowMap rm, int M, int D, float* out, hipStream_t s);
+int launch_cast_bf16(const float* in, bf16_t* out, size_t n, hipStream_t s);
+int launch_gather_rows_bf16(const float* in, RowMap rm, bf16_t* out, int M, int D, hipStream_t s);
+int launch_mask_index(const uint8_t* mask, int B, int L, int nvis, int nmask, int* vis_idx, int* msk_idx, int* status, hipStream_t s);
+int launch_gather_patches(const float* clip, const int* vis_idx, bf16_t* A, int B, int nvis, PatchGeom pg, hipStream_t s);
+int launch_labels(const float* clip, const int* msk_idx, float* labels, int B, int nmask, PatchGeom pg, int norm_pix, hipStream_t s);
+int launch_fill_masked(float* xfull, const float* mask_token, const float* pos, const int* msk_idx, int B, int L, int nvis,
+                       int nmask, int D, hipStream_t s);
+int launch_loss_finalize(const float* partial, int n, double count, const int* status, float* loss, hipStream_t s);
+
+}  // namespace bvc

@@ -1,0 +1,406 @@
+// HBM-bound row / element kernels of the ViT step (gfx950): LayerNorm fwd/bwd, column sums for
+// bias gradients, parameter cast, mask -> index lists, tube-patch gather, pixel targets, decoder
+// input fill, loss finalize.  All are one-pass streaming kernels with 8-16 B per lane accesses.
+#include "rowops.h"
+
+namespace bvc {
+
+constexpr int kMaxChunks = 4;   // float4 chunks per lane: D <= 1024
+
+__device__ __forceinline__ int map_row(int m, RowMap rm) {
+    return rm.rin > 0 ? (m / rm.rin) * rm.rout + rm.roff + (m % rm.rin) : m;
+}
+
+// ============================================================================ LayerNorm forward
+// one wave per row; y = (x - mean) * rstd * gamma + beta in bf16; saves mean / rstd (biased variance,
+// torch.nn.LayerNorm semantics, HF:336-337)
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, RowMap rm, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, bf16_t* __restrict__ y,
+                                                     float* __restrict__ mean, float* __restrict__ rstd, int M, int D, float eps) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m = blockIdx.x * 4 + wave;
+    if (m >= M) return;
+    const int nch = D >> 2;
+    const f32x4* xr = reinterpret_cast<const f32x4*>(x + (size_t)map_row(m, rm) * D);
+    f32x4 v[kMaxChunks];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < kMaxChunks; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nch) { v[i] = xr[c]; s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]); }
+    }
+    const float mu = wave_sum(s) / D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < kMaxChunks; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nch) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mu; q += d * d; }
+        }
+    }
+    const float rs = rsqrtf(wave_sum(q) / D + eps);
+    if (lane == 0) { mean[m] = mu; rstd[m] = rs; }
+    uint2* yr = reinterpret_cast<uint2*>(y + (size_t)m * D);
+#pragma unroll
+    for (int i = 0; i < kMaxChunks; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nch) {
+            const f32x4 g = reinterpret_cast<const f32x4*>(gamma)[c];
+            const f32x4 b = reinterpret_cast<const f32x4*>(beta)[c];
+            const f32x4 o = (v[i] - mu) * rs * g + b;
+            yr[c] = uint2{pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
+        }
+    }
+}
+
+// ============================================================================ LayerNorm backward
+// dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma;  dres (+)= dx; optional bf16 copy;
+// dgamma += sum_rows dy * xhat, dbeta += sum_rows dy  (block-reduced, then one atomicAdd per column)
+template <int RPB>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ dy, const float* __restrict__ x, RowMap rm,
+                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                     const float* __restrict__ gamma, float* __restrict__ dres,
+                                                     int accumulate, bf16_t* __restrict__ dres_bf, float* __restrict__ dgamma,
+                                                     float* __restrict__ dbeta, int M, int D) {
+    __shared__ float red[4][2][kMaxChunks * 256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nch = D >> 2;
+    f32x4 gam[kMaxChunks], dg[kMaxChunks], db[kMaxChunks];
+#pragma unroll
+    for (int i = 0; i < kMaxChunks; ++i) {
+        const int c = lane + 64 * i;
+        gam[i] = c < nch ? reinterpret_cast<const f32x4*>(gamma)[c] : f32x4{0, 0, 0, 0};
+        dg[i] = f32x4{0, 0, 0, 0};
+        db[i] = f32x4{0, 0, 0, 0};
+    }
+    const float invD = 1.f / D;
+    for (int it = 0; it < RPB / 4; ++it) {
+        const int m = blockIdx.x * RPB + it * 4 + wave;
+        if (m >= M) break;
+        const size_t xrow = (size_t)map_row(m, rm) * D;
+        const f32x4* xr = reinterpret_cast<const f32x4*>(x + xrow);
+        const uint2* dyr = reinterpret_cast<const uint2*>(dy + (size_t)m * D);
+        const float mu = mean[m], rs = rstd[m];
+        f32x4 xh[kMaxChunks], g[kMaxChunks];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < kMaxChunks; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nch) {
+                const uint2 d = dyr[c];
+                const f32x4 dyv = {__uint_as_float(d.x << 16), __uint_as_float(d.x & 0xffff0000u),
+                                   __uint_as_float(d.y << 16), __uint_as_float(d.y & 0xffff0000u)};
+                xh[i] = (xr[c] - mu) * rs;
+                g[i] = dyv * gam[i];
+                dg[i] += dyv * xh[i];
+                db[i] += dyv;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { s1 += g[i][e]; s2 += g[i][e] * xh[i][e]; }
+            }
+        }
+        s1 = wave_sum(s1) * invD;
+        s2 = wave_sum(s2) * invD;
+        f32x4* dr = reinterpret_cast<f32x4*>(dres + xrow);
+        uint2* db16 = dres_bf ? reinterpret_cast<uint2*>(dres_bf + xrow) : nullptr;
+#pragma unroll
+        for (int i = 0; i < kMaxChunks; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nch) {
+                f32x4 dx = (g[i] - s1 - xh[i] * s2) * rs;
+                if (accumulate) dx += dr[c];
+                dr[c] = dx;
+                if (db16) db16[c] = uint2{pack2bf(dx[0], dx[1]), pack2bf(dx[2], dx[3])};
+            }
+        }
+    }
+    // cross-wave reduction of the column partials, then one atomic per column per workgroup
+#pragma unroll
+    for (int i = 0; i < kMaxChunks; ++i) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            red[wave][0][(lane + 64 * i) * 4 + e] = dg[i][e];
+            red[wave][1][(lane + 64 * i) * 4 + e] = db[i][e];
+        }
+    }
+    __syncthreads();
+    for (int col = threadIdx.x; col < D; col += 256) {
+        const float a = (red[0][0][col] + red[1][0][col]) + (red[2][0][col] + red[3][0][col]);
+        const float b = (red[0][1][col] + red[1][1][col]) + (red[2][1][col] + red[3][1][col]);
+        atomicAdd(dgamma + col, a);
+        atomicAdd(dbeta + col, b);
+    }
+}
+
+// ============================================================================ column sums
+// out[n] += alpha * sum_m X[m][n]   (bias gradients), X bf16 [M][ld]; grid (ceil(N/512), ceil(M/RB))
+__global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* __restrict__ X, int M, int N, int ld, float alpha,
+                                                          const float* __restrict__ alpha_dev, float* __restrict__ out, int RB) {
+    __shared__ float red[4][512];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = (blockIdx.x * 64 + lane) * 8;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int r0 = blockIdx.y * RB, r1 = min(M, r0 + RB);
+    if (col < N) {
+        for (int m = r0 + wave; m < r1; m += 4) {
+            const bf16x8 v = *reinterpret_cast<const bf16x8*>(X + (size_t)m * ld + col);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += bf2f((bf16_t)v[e]);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[wave][lane * 8 + e] = acc[e];
+    __syncthreads();
+    for (int c = threadIdx.x; c < 512; c += 256) {
+        const int n = blockIdx.x * 512 + c;
+        if (n < N) atomicAdd(out + n, (alpha_dev ? alpha * alpha_dev[0] : alpha) * ((red[0][c] + red[1][c]) + (red[2][c] + red[3][c])));
+    }
+}
+
+// out[n] += sum over mapped rows of X f32 [..][D]   (mask-token gradient); grid (ceil(D/256), ceil(M/RB))
+__global__ __launch_bounds__(256) void colsum_f32_kernel(const float* __restrict__ X, RowMap rm, int M, int D,
+                                                         float* __restrict__ out, int RB) {
+    __shared__ float red[4][256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = (blockIdx.x * 64 + lane) * 4;
+    f32x4 acc = {0, 0, 0, 0};
+    const int r0 = blockIdx.y * RB, r1 = min(M, r0 + RB);
+    if (col < D)
+        for (int m = r0 + wave; m < r1; m += 4)
+            acc += *reinterpret_cast<const f32x4*>(X + (size_t)map_row(m, rm) * D + col);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[wave][lane * 4 + e] = acc[e];
+    __syncthreads();
+    const int c = threadIdx.x;
+    const int n = blockIdx.x * 256 + c;
+    if (n < D) atomicAdd(out + n, (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]));
+}
+
+// ============================================================================ elementwise
+__global__ void cast_f32_bf16_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, size_t n) {
+    const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+    if (i + 8 <= n) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(in + i);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(in + i + 4);
+        *reinterpret_cast<uint4*>(out + i) = uint4{pack2bf(a[0], a[1]), pack2bf(a[2], a[3]), pack2bf(b[0], b[1]), pack2bf(b[2], b[3])};
+    } else {
+        for (size_t j = i; j < n; ++j) out[j] = f2bf(in[j]);
+    }
+}
+
+// out bf16 [M][D] = in f32 [map_row(m)][D]
+__global__ void gather_rows_bf16_kernel(const float* __restrict__ in, RowMap rm, bf16_t* __restrict__ out, int M, int D) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // float4 item
+    const int nch = D >> 2;
+    if (i >= (size_t)M * nch) return;
+    const int m = (int)(i / nch), c = (int)(i % nch);
+    const f32x4 v = *reinterpret_cast<const f32x4*>(in + (size_t)map_row(m, rm) * D + c * 4);
+    *reinterpret_cast<uint2*>(out + (size_t)m * D + c * 4) = uint2{pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+}
+
+// ============================================================================ mask -> ordered index lists
+// one wave per clip: ascending token order for both lists (boolean-mask gather order, HF:121,578-579,661)
+__global__ void mask_index_kernel(const uint8_t* __restrict__ mask, int L, int nvis, int nmask, int* __restrict__ vis_idx,
+                                  int* __restrict__ msk_idx, int* __restrict__ status) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    int nv = 0, nm = 0;
+    const unsigned long long below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    for (int base = 0; base < L; base += 64) {
+        const int t = base + lane;
+        const bool in = t < L;
+        const bool mk = in && mask[(size_t)b * L + t] != 0;
+        const unsigned long long bm = __ballot(mk), bv = __ballot(in && !mk);
+        if (mk) { const int p = nm + __popcll(bm & below); if (p < nmask) msk_idx[(size_t)b * nmask + p] = t; }
+        if (in && !mk) { const int p = nv + __popcll(bv & below); if (p < nvis) vis_idx[(size_t)b * nvis + p] = t; }
+        nm += __popcll(bm);
+        nv += __popcll(bv);
+    }
+    if (lane == 0 && (nv != nvis || nm != nmask)) atomicOr(status, 1);
+}
+
+// ============================================================================ tube-patch gather (visible tokens only)
+// A[m][k], k = ((c*ts + dt)*ps + dy)*ps + dx  (Conv3d weight order, HF:157-162), clip f32 [B][T][C][H][W]
+__global__ void gather_patches_kernel(const float* __restrict__ clip, const int* __restrict__ vis_idx, bf16_t* __restrict__ A,
+                                      int B, int nvis, PatchGeom pg) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int K = pg.C * pg.ts * pg.ps * pg.ps;
+    const int k8 = K >> 3;
+    if (i >= (size_t)B * nvis * k8) return;
+    const int m = (int)(i / k8);
+    const int k = (int)(i % k8) * 8;
+    const int dx = k % pg.ps, dy = (k / pg.ps) % pg.ps, dt = (k / (pg.ps * pg.ps)) % pg.ts, c = k / (pg.ps * pg.ps * pg.ts);
+    const int b = m / nvis, tok = vis_idx[m];
+    const int wp = pg.W / pg.ps, hp = pg.H / pg.ps;
+    const int tp = tok / (hp * wp), yp = (tok / wp) % hp, xp = tok % wp;
+    const size_t src = ((((size_t)b * pg.T + tp * pg.ts + dt) * pg.C + c) * pg.H + yp * pg.ps + dy) * pg.W + xp * pg.ps + dx;
+    const f32x4 a = *reinterpret_cast<const f32x4*>(clip + src);
+    const f32x4 d = *reinterpret_cast<const f32x4*>(clip + src + 4);
+    *reinterpret_cast<uint4*>(A + (size_t)m * K + k) =
+        uint4{pack2bf(a[0], a[1]), pack2bf(a[2], a[3]), pack2bf(d[0], d[1]), pack2bf(d[2], d[3])};
+}
+
+// ============================================================================ pixel targets (HF:588-661)
+// one workgroup per masked token: un-normalise, per-channel mean / unbiased variance over ts*ps*ps
+// values, labels[(dt,dy,dx,c)] = (f - mean) / (sqrt(var) + 1e-6)
+__global__ __launch_bounds__(256) void labels_kernel(const float* __restrict__ clip, const int* __restrict__ msk_idx,
+                                                     float* __restrict__ labels, int nmask, PatchGeom pg, int norm_pix) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* buf = reinterpret_cast<float*>(smem);   // [C][E]
+    const int E = pg.ts * pg.ps * pg.ps, C = pg.C;
+    float* stat = buf + C * E;                     // [C][2]
+    const int m = blockIdx.x, b = m / nmask, tok = msk_idx[m];
+    const int wp = pg.W / pg.ps, hp = pg.H / pg.ps;
+    const int tp = tok / (hp * wp), yp = (tok / wp) % hp, xp = tok % wp;
+    const float mean3[3] = {0.485f, 0.456f, 0.406f}, std3[3] = {0.229f, 0.224f, 0.225f};
+    const int e4n = E >> 2;
+    for (int i = threadIdx.x; i < C * e4n; i += 256) {
+        const int c = i / e4n, e = (i % e4n) * 4;
+        const int dx = e % pg.ps, dy = (e / pg.ps) % pg.ps, dt = e / (pg.ps * pg.ps);
+        const size_t src = ((((size_t)b * pg.T + tp * pg.ts + dt) * C + c) * pg.H + yp * pg.ps + dy) * pg.W + xp * pg.ps + dx;
+        f32x4 v = *reinterpret_cast<const f32x4*>(clip + src);
+        if (C == 3) v = v * std3[c] + mean3[c];
+        *reinterpret_cast<f32x4*>(buf + c * E + e) = v;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int c = wave; c < C; c += 4) {
+        float s = 0.f;
+        for (int e = lane; e < E; e += 64) s += buf[c * E + e];
+        const float mu = wave_sum(s) / E;
+        float q = 0.f;
+        for (int e = lane; e < E; e += 64) { const float d = buf[c * E + e] - mu; q += d * d; }
+        const float var = wave_sum(q) / (E - 1);
+        if (lane == 0) { stat[2 * c] = norm_pix ? mu : 0.f; stat[2 * c + 1] = norm_pix ? sqrtf(var) + 1e-6f : 1.f; }
+    }
+    __syncthreads();
+    float* out = labels + (size_t)m * C * E;
+    for (int o = threadIdx.x * 4; o < C * E; o += 1024) {
+        f32x4 r;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int e = (o + j) / C, c = (o + j) % C;
+            r[j] = (buf[c * E + e] - stat[2 * c]) / stat[2 * c + 1];
+        }
+        *reinterpret_cast<f32x4*>(out + o) = r;
+    }
+}
+
+// x_full[b][nvis + j][:] = mask_token + pos[msk_idx[b][j]]   (HF:580-582)
+__global__ void fill_masked_kernel(float* __restrict__ xfull, const float* __restrict__ mask_token, const float* __restrict__ pos,
+                                   const int* __restrict__ msk_idx, int B, int L, int nvis, int nmask, int D) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int nch = D >> 2;
+    if (i >= (size_t)B * nmask * nch) return;
+    const int m = (int)(i / nch), c = (int)(i % nch);
+    const int b = m / nmask, j = m % nmask;
+    const f32x4 mt = reinterpret_cast<const f32x4*>(mask_token)[c];
+    const f32x4 pe = reinterpret_cast<const f32x4*>(pos + (size_t)msk_idx[m] * D)[c];
+    reinterpret_cast<f32x4*>(xfull + ((size_t)b * L + nvis + j) * D)[c] = mt + pe;
+}
+
+// loss = sum(partials) / count, fixed summation order; NaN if the mask index kernel flagged a bad mask
+__global__ __launch_bounds__(256) void loss_finalize_kernel(const float* __restrict__ partial, int n, double count,
+                                                            const int* __restrict__ status, float* __restrict__ loss) {
+    __shared__ double red[256];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) s += (double)partial[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *loss = (status && *status) ? __int_as_float(0x7fc00000) : (float)(red[0] / count);
+}
+
+// ============================================================================ launchers
+static inline unsigned blocks_for(size_t items, int per = 256) { return (unsigned)((items + per - 1) / per); }
+
+int launch_ln_fwd(const float* x, RowMap rm, const float* gamma, const float* beta, bf16_t* y, float* mean, float* rstd,
+                  int M, int D, float eps, hipStream_t s) {
+    BVC_REQUIRE(D % 4 == 0 && D <= kMaxChunks * 256, "ln_fwd: D=%d unsupported", D);
+    hipLaunchKernelGGL(ln_fwd_kernel, dim3((M + 3) / 4), dim3(256), 0, s, x, rm, gamma, beta, y, mean, rstd, M, D, eps);
+    BVC_CHECK_HIP(hipGetLastError());
+    return BVC_OK;
+}
+
+int launch_ln_bwd(const bf16_t* dy, const float* x, RowMap rm, const float* mean, const float* rstd, const float* gamma,
+                  float* dres, int accumulate, bf16_t* dres_bf, float* dgamma, float* dbeta, int M, int D, hipStream_t s) {
+    BVC_REQUIRE(D % 4 == 0 && D <= kMaxChunks * 256, "ln_bwd: D=%d unsupported", D);
+    if (M >= 16384)
+        hipLaunchKernelGGL(ln_bwd_kernel<64>, dim3((M + 63) / 64), dim3(256), 0, s, dy, x, rm, mean, rstd, gamma, dres, accumulate, dres_bf, dgamma, dbeta, M, D);
+    else
+        hipLaunchKernelGGL(ln_bwd_kernel<16>, dim3((M + 15) / 16), dim3(256), 0, s, dy, x, rm, mean, rstd, gamma, dres, accumulate, dres_bf, dgamma, dbeta, M, D);
+    BVC_CHECK_HIP(hipGetLastError());
+    return BVC_OK;
+}
+
+int launch_colsum_bf16_scaled(const bf16_t* X, int M, int N, int ld, float alpha, const float* alpha_dev, float* out, hipStream_t s) {
+    BVC_REQUIRE(N % 8 == 0 && ld % 8 == 0, "colsum_bf16: N and ld must be multiples of 8");
+    const int RB = M >= 16384 ? 256 : 64;
+    hipLaunchKernelGGL(colsum_bf16_kernel, dim3((N + 511) / 512, (M + RB - 1) / RB), dim3(256), 0, s, X, M, N, ld, alpha, alpha_dev, out, RB);
+    BVC_CHECK_HIP(hipGetLastError());
+    return BVC_OK;
+}
+
+int launch_colsum_bf16(const bf16_t* X, int M, int N, int ld, float alpha, float* out, hipStream_t s) {
+    return launch_colsum_bf16_scaled(X, M, N, ld, alpha, nullptr, out, s);
+}
+
+int launch_colsum_f32(const float* X, RowMap rm, int M, int D, float* out, hipStream_t s) {
+    BVC_REQUIRE(D % 4 == 0, "colsum_f32: D must be a multiple of 4");
+    const int RB = 256;
+    hipLaunchKernelGGL(colsum_f32_kernel, dim3((D + 255) / 256, (M + RB - 1) / RB), dim3(256), 0, s, X, rm, M, D, out, RB);
+    BVC_CHECK_HIP(hipGetLastError());
+    return BVC_OK;
+}
+
+int launch_cast_bf16(const float* in, bf16_t* out, size_t n, hipStream_t s) {
+    hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(blocks_for((n + 7) / 8)), dim3(256), 0, s, in, out, n);
+    BVC_CHECK_HIP(hipGetLastError());
+    return BVC_OK;
+}
+
+int launch_gather_rows_bf16(const float* in, RowMap rm, bf16_t* out, int M, int D, hipStream_t s) {
+    hipLaunchKernelGGL(gather_rows_bf16_kernel, dim3(blocks_for((size_t)M * (D / 4))), dim3(256), 0, s, in, rm, out, M, D);
+    BVC_CHECK_HIP(hipGetLastError());
+    return BVC_OK;
+}
+
+int launch_mask_index(const uint8_t* mask, int B, int L, int nvis, int nmask, int* vis_idx, int* msk_idx, int* status, hipStream_t s) {
+    hipLaunchKernelGGL(mask_index_kernel, dim3(B), dim3(64), 0, s, mask, L, nvis, nmask, vis_idx, msk_idx, status);
+    BVC_CHECK_HIP(hipGetLastError());
+    return BVC_OK;
+}
+
+int launch_gather_patches(const float* clip, const int* vis_idx, bf16_t* A, int B, int nvis, PatchGeom pg, hipStream_t s) {
+    BVC_REQUIRE(pg.ps % 8 == 0 && pg.W % 4 == 0, "gather_patches: patch size must be a multiple of 8");
+    const size_t items = (size_t)B * nvis * (pg.C * pg.ts * pg.ps * pg.ps / 8);
+    hipLaunchKernelGGL(gather_patches_kernel, dim3(blocks_for(items)), dim3(256), 0, s, clip, vis_idx, A, B, nvis, pg);
+    BVC_CHECK_HIP(hipGetLastError());
+    return BVC_OK;
+}
+
+int launch_labels(const float* clip, const int* msk_idx, float* labels, int B, int nmask, PatchGeom pg, int norm_pix, hipStream_t s) {
+    BVC_REQUIRE(pg.ps % 4 == 0, "labels: patch size must be a multiple of 4");
+    const int E = pg.ts * pg.ps * pg.ps;
+    const size_t lds = (size_t)(pg.C * E + 2 * pg.C) * 4;
+    hipLaunchKernelGGL(labels_kernel, dim3(B * nmask), dim3(256), lds, s, clip, msk_idx, labels, nmask, pg, norm_pix);
+    BVC_CHECK_HIP(hipGetLastError());
+    return BVC_OK;
+}
+
+int launch_fill_masked(float* xfull, const float* mask_token, const float* pos, const int* msk_idx, int B, int L, int nvis,
+                       int nmask, int D, hipStream_t s) {
+    hipLaunchKernelGGL(fill_masked_kernel, dim3(blocks_for((size_t)B * nmask * (D / 4))), dim3(256), 0, s, xfull, mask_token, pos, msk_idx, B, L, nvis, nmask, D);
+    BVC_CHECK_HIP(hipGetLastError());
+    return BVC_OK;
+}
+
+int launch_loss_finalize(const float* partial, int n, double count, const int* status, float* loss, hipStream_t s) {
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, s, partial, n, count, status, loss);
+    BVC_CHECK_HIP(hipGetLastError());
+    return BVC_OK;
+}
+
+}  // namespace bvc

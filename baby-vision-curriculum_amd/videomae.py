@@ -1,0 +1,312 @@
+"""VideoMAE pre-training model object with the interface the reference's entry point uses.
+
+Reference seam (pretraining/generative/pretrain_videomae.py):
+  :43-64   get_config / get_model  -> transformers.VideoMAEConfig / VideoMAEForPreTraining
+  :66-70   load_state_dict(ckpt['model_state_dict'])        (transformers key names)
+  :170-176 model.config.image_size / patch_size / num_frames / tubelet_size
+  :178-181 .to(rank), DDP(model), .parameters(), .train(), .eval()
+  :301-302 outputs = xmodel(inputs, bool_masked_pos=m); outputs.loss
+  :312     scaler.scale(loss).backward()
+The arithmetic (HF:531-671) runs in libbvc_hip.so; this file only owns parameters, the flat
+parameter / gradient buffers and the autograd bridge.
+"""
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+
+class VideoMAEConfig:
+    """The fields of transformers.VideoMAEConfig that the path reads; unknown kwargs are kept as attributes."""
+
+    def __init__(self, image_size=224, patch_size=16, num_channels=3, num_frames=16, tubelet_size=2,
+                 hidden_size=768, num_hidden_layers=12, num_attention_heads=12, intermediate_size=3072,
+                 hidden_act="gelu", layer_norm_eps=1e-12, initializer_range=0.02, qkv_bias=True,
+                 use_mean_pooling=True, decoder_num_attention_heads=6, decoder_hidden_size=384,
+                 decoder_num_hidden_layers=4, decoder_intermediate_size=1536, norm_pix_loss=True, **kwargs):
+        if hidden_act != "gelu":
+            raise ValueError("only hidden_act='gelu' (exact erf GELU) is implemented")
+        if not qkv_bias:
+            raise ValueError("qkv_bias=False is not implemented")
+        self.image_size, self.patch_size, self.num_channels = image_size, patch_size, num_channels
+        self.num_frames, self.tubelet_size = num_frames, tubelet_size
+        self.hidden_size, self.num_hidden_layers = hidden_size, num_hidden_layers
+        self.num_attention_heads, self.intermediate_size = num_attention_heads, intermediate_size
+        self.hidden_act, self.layer_norm_eps, self.initializer_range = hidden_act, layer_norm_eps, initializer_range
+        self.qkv_bias, self.use_mean_pooling = qkv_bias, use_mean_pooling
+        self.decoder_num_attention_heads, self.decoder_hidden_size = decoder_num_attention_heads, decoder_hidden_size
+        self.decoder_num_hidden_layers, self.decoder_intermediate_size = decoder_num_hidden_layers, decoder_intermediate_size
+        self.norm_pix_loss = norm_pix_loss
+        self.decoder_norm_eps = 1e-5   # nn.LayerNorm default used by decoder.norm (HF:484)
+        for k, v in kwargs.items():
+            setattr(self, k, v)
+
+    @property
+    def seq_length(self):
+        g = self.image_size // self.patch_size
+        return (self.num_frames // self.tubelet_size) * g * g
+
+    def to_c(self) -> _lib.VideoMAEConfigC:
+        return _lib.VideoMAEConfigC(
+            self.image_size, self.patch_size, self.num_channels, self.num_frames, self.tubelet_size,
+            self.hidden_size, self.num_hidden_layers, self.num_attention_heads, self.intermediate_size,
+            self.decoder_hidden_size, self.decoder_num_hidden_layers, self.decoder_num_attention_heads,
+            self.decoder_intermediate_size, float(self.layer_norm_eps), float(self.decoder_norm_eps),
+            int(bool(self.norm_pix_loss)))
+
+
+@dataclass
+class VideoMAEForPreTrainingOutput:
+    loss: Optional[torch.Tensor] = None
+    logits: Optional[torch.Tensor] = None
+    hidden_states: Optional[tuple] = None
+    attentions: Optional[tuple] = None
+
+
+def param_layout(config: VideoMAEConfig):
+    """[(state-dict key, offset, shape)] in flat-buffer order, as libbvc_hip.so defines it."""
+    L = _lib.lib()
+    cc = config.to_c()
+    n = L.bvc_videomae_param_count(ctypes.byref(cc))
+    if n <= 0:
+        _lib.check(n if n < 0 else -1, "bvc_videomae_param_count")
+    out = []
+    name = ctypes.create_string_buffer(256)
+    off, numel, ndim = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int()
+    shape = (ctypes.c_int64 * 5)()
+    for i in range(n):
+        _lib.check(L.bvc_videomae_param_info(ctypes.byref(cc), i, name, 256, ctypes.byref(off), ctypes.byref(numel),
+                                             ctypes.byref(ndim), shape), "bvc_videomae_param_info")
+        out.append((name.value.decode(), int(off.value), tuple(int(shape[j]) for j in range(ndim.value))))
+    return out, int(L.bvc_videomae_param_numel(ctypes.byref(cc)))
+
+
+class _Step(torch.autograd.Function):
+    """loss = step(pixels, mask); backward fills the flat gradient buffer and hands out views as .grad."""
+
+    @staticmethod
+    def forward(ctx, anchor, model, pixels, mask, want_logits):
+        ctx.model = model
+        loss, logits = model._run_forward(pixels, mask, want_logits)
+        ctx.mark_non_differentiable(logits) if logits is not None else None
+        return loss, logits
+
+    @staticmethod
+    def backward(ctx, grad_loss, _grad_logits):
+        ctx.model._run_backward(grad_loss)
+        return None, None, None, None, None
+
+
+class VideoMAEForPreTraining(nn.Module):
+    """Drop-in for transformers.VideoMAEForPreTraining on the pre-training path (same state-dict keys)."""
+
+    def __init__(self, config: VideoMAEConfig):
+        super().__init__()
+        self.config = config
+        self._layout, self._numel = param_layout(config)
+        self._names = []
+        gen_std = config.initializer_range
+        for name, _off, shape in self._layout:
+            # transformers' _init_weights: normal(0, initializer_range) for Linear/Conv3d weights,
+            # zero biases, LayerNorm weight 1 / bias 0; mask_token is created as zeros (HF:515)
+            if len(shape) >= 2 and name != "mask_token":
+                t = torch.empty(shape).normal_(0.0, gen_std)
+            elif name.endswith("layernorm_before.weight") or name.endswith("layernorm_after.weight") or name == "decoder.norm.weight":
+                t = torch.ones(shape)
+            else:
+                t = torch.zeros(shape)
+            self._register(name, nn.Parameter(t))
+            self._names.append(name)
+        self._flat = None        # f32 flat parameter buffer (device); parameters are views into it
+        self._flat_grad = None   # f32 flat gradient buffer
+        self._ctx = None
+        self._ctx_key = None
+        self._bucket_hook = None   # set by the data-parallel wrapper: fn(offset, count)
+        self._after_backward = None
+        self.strict_mask_check = False
+        self._nmask_cache = {}
+
+    # ---- parameters live under transformers' dotted names
+    def _register(self, dotted, param):
+        mod = self
+        parts = dotted.split(".")
+        for p in parts[:-1]:
+            if p not in mod._modules:
+                mod.add_module(p, nn.Module())
+            mod = mod._modules[p]
+        mod.register_parameter(parts[-1], param)
+
+    def _param(self, dotted):
+        mod = self
+        parts = dotted.split(".")
+        for p in parts[:-1]:
+            mod = mod._modules[p]
+        return mod._parameters[parts[-1]]
+
+    # ---- flat buffers
+    def _ensure_flat(self, device):
+        """Make every parameter a view into one contiguous f32 buffer in the library's layout.
+        Re-done whenever .to()/load_state_dict replaced parameter storage."""
+        flat = self._flat
+        ok = flat is not None and flat.device == device
+        if ok:
+            base = flat.data_ptr()
+            for name, off, _shape in self._layout:
+                if self._param(name).data_ptr() != base + 4 * off:
+                    ok = False
+                    break
+        if ok:
+            return
+        new = torch.empty(self._numel, dtype=torch.float32, device=device)
+        for name, off, shape in self._layout:
+            p = self._param(name)
+            n = p.numel()
+            new[off:off + n].copy_(p.data.reshape(-1).to(device=device, dtype=torch.float32))
+            p.data = new[off:off + n].view(shape)
+            p.grad = None
+        self._flat = new
+        self._flat_grad = None
+
+    def flat_parameters(self):
+        if self._flat is None:
+            raise RuntimeError("parameters are flattened on the first forward on a GPU (or call _ensure_flat(device))")
+        return self._flat
+
+    def flat_grads(self):
+        if self._flat_grad is None:
+            self._flat_grad = torch.zeros_like(self.flat_parameters())
+        return self._flat_grad
+
+    # ---- library context
+    def _get_ctx(self, batch, nmask):
+        key = (batch, nmask, self._flat.device.index)
+        if self._ctx is not None and self._ctx_key[1] == nmask and self._ctx_key[2] == key[2] and self._ctx_key[0] >= batch:
+            return self._ctx
+        self._free_ctx()
+        h = ctypes.c_void_p()
+        cc = self.config.to_c()
+        _lib.check(_lib.lib().bvc_videomae_create(ctypes.byref(cc), batch, nmask, ctypes.byref(h)), "bvc_videomae_create")
+        self._ctx, self._ctx_key = h, key
+        return h
+
+    def _free_ctx(self):
+        if self._ctx is not None:
+            _lib.lib().bvc_videomae_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self._free_ctx()
+        except Exception:
+            pass
+
+    # ---- step
+    def _num_masked(self, mask):
+        key = tuple(mask.shape)
+        if self.strict_mask_check or key not in self._nmask_cache:
+            counts = mask.sum(dim=1)
+            n = int(counts[0])       # one host sync, first call per shape only
+            if self.strict_mask_check and not bool((counts == n).all()):
+                raise ValueError("every clip must have the same number of masked patches")
+            self._nmask_cache[key] = n
+        return self._nmask_cache[key]
+
+    def _run_forward(self, pixels, mask, want_logits):
+        cfg = self.config
+        B = pixels.shape[0]
+        nmask = self._num_masked(mask)
+        h = self._get_ctx(B, nmask)
+        loss = torch.empty((), dtype=torch.float32, device=pixels.device)
+        logits = None
+        if want_logits:
+            pd = cfg.num_channels * cfg.tubelet_size * cfg.patch_size ** 2
+            logits = torch.empty((B, nmask, pd), dtype=torch.float32, device=pixels.device)
+        _lib.check(_lib.lib().bvc_videomae_forward(
+            h, pixels.data_ptr(), mask.data_ptr(), B, self._flat.data_ptr(), loss.data_ptr(),
+            logits.data_ptr() if logits is not None else None, _lib.current_stream_ptr()), "bvc_videomae_forward")
+        self._live = (pixels, mask)   # keep the borrowed inputs alive until backward
+        return loss, logits
+
+    def _run_backward(self, grad_loss):
+        G = self.flat_grads()
+        accumulate = any(self._param(n).grad is not None for n in (self._names[0], self._names[-1]))
+        target = torch.empty_like(G) if accumulate else G
+        g = grad_loss.detach().to(dtype=torch.float32).contiguous()
+        hook = self._bucket_hook if not accumulate else None
+        if hook is not None:
+            def _cb(offset, count, _user, _hook=hook):
+                _hook(int(offset), int(count))
+            cb = _lib.BUCKET_FN(_cb)
+        else:
+            cb = ctypes.cast(None, _lib.BUCKET_FN)
+        _lib.check(_lib.lib().bvc_videomae_backward(self._ctx, g.data_ptr(), target.data_ptr(), cb, None,
+                                                    _lib.current_stream_ptr()), "bvc_videomae_backward")
+        if accumulate:
+            G.add_(target)
+            if self._bucket_hook is not None:
+                self._bucket_hook(0, self._numel)
+        else:
+            for name, off, shape in self._layout:
+                p = self._param(name)
+                n = p.numel()
+                p.grad = G[off:off + n].view(shape)
+        if self._after_backward is not None:
+            self._after_backward()
+        self._live = None
+
+    def forward(self, pixel_values, bool_masked_pos=None, output_logits=False, **kwargs):
+        if bool_masked_pos is None:
+            raise ValueError("One must provided a boolean mask ")
+        if not pixel_values.is_cuda:
+            raise _lib.BvcError("VideoMAEForPreTraining runs on a GPU only (libbvc_hip.so has no CPU path)")
+        cfg = self.config
+        B, T, C, H, W = pixel_values.shape
+        if C != cfg.num_channels:
+            raise ValueError("Make sure that the channel dimension of the pixel values match with the one set in the configuration.")
+        if H != cfg.image_size or W != cfg.image_size or T != cfg.num_frames:
+            raise ValueError(f"Input size ({T}x{H}*{W}) doesn't match model ({cfg.num_frames}x{cfg.image_size}*{cfg.image_size}).")
+        if tuple(bool_masked_pos.shape) != (B, cfg.seq_length):
+            raise ValueError(f"bool_masked_pos must have shape {(B, cfg.seq_length)}")
+        self._ensure_flat(pixel_values.device)
+        pixels = pixel_values.detach().to(dtype=torch.float32).contiguous()
+        mask = bool_masked_pos.to(device=pixels.device, dtype=torch.bool).contiguous()
+        anchor = self._param(self._names[0])
+        if torch.is_grad_enabled() and anchor.requires_grad:
+            loss, logits = _Step.apply(anchor, self, pixels, mask, output_logits)
+        else:
+            loss, logits = self._run_forward(pixels, mask, output_logits)
+        return VideoMAEForPreTrainingOutput(loss=loss, logits=logits)
+
+    # ---- parity probes
+    def tap(self, name):
+        """f32 copy of a saved activation of the last forward ('embed', 'enc<i>', 'x_full', 'dec<i>', 'labels')."""
+        cfg = self.config
+        cap = max(self._ctx_key[0] * cfg.seq_length * max(cfg.hidden_size, cfg.decoder_hidden_size),
+                  self._ctx_key[0] * self._ctx_key[1] * cfg.num_channels * cfg.tubelet_size * cfg.patch_size ** 2)
+        buf = torch.empty(cap, dtype=torch.float32, device=self._flat.device)
+        n = ctypes.c_int64()
+        _lib.check(_lib.lib().bvc_videomae_tap(self._ctx, name.encode(), buf.data_ptr(), cap, ctypes.byref(n),
+                                               _lib.current_stream_ptr()), "bvc_videomae_tap")
+        return buf[: n.value]
+
+
+def get_config(image_size, args):
+    """pretrain_videomae.py:43-58 (only architecture='base' exists in the reference)."""
+    if getattr(args, "architecture", "base") != "base":
+        raise ValueError("only architecture='base' is defined by the reference")
+    return VideoMAEConfig(image_size=image_size, patch_size=16, num_channels=3, num_frames=args.num_frames,
+                          tubelet_size=args.tubelet_size, hidden_size=768, num_hidden_layers=12,
+                          num_attention_heads=12, intermediate_size=3072, initializer_range=0.02,
+                          use_mean_pooling=True, decoder_num_attention_heads=6, decoder_hidden_size=384,
+                          decoder_num_hidden_layers=4, decoder_intermediate_size=1536, norm_pix_loss=True)
+
+
+def get_model(image_size, args):
+    """pretrain_videomae.py:61-64"""
+    return VideoMAEForPreTraining(get_config(image_size, args))

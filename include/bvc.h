@@ -1,0 +1,143 @@
+/* libbvc_hip.so -- C ABI of the MI355X-native (gfx950) self-supervised video pre-training step.
+ *
+ * The reference (ssheybani/baby-vision-curriculum) is pure Python and has no FFI of its own: its
+ * entry points call a model object.  This header is the boundary a maintainer binds (ctypes stub in
+ * INTEGRATION.md) so that object's arithmetic runs as hand-written HIP.  Each entry point cites the
+ * reference interface it replaces; paths are relative to the reference checkout, "HF" is
+ * transformers/models/videomae/modeling_videomae.py (5.15.0), which the reference instantiates at
+ * pretraining/generative/pretrain_videomae.py:61-64.
+ *
+ * Conventions
+ *  - every function returns 0 (BVC_OK) or a negative bvc_status; bvc_last_error() returns a
+ *    thread-local message.  No C++ exception crosses this boundary, HIP errors are translated.
+ *  - all pointers named *_dev are device pointers borrowed from the caller (torch tensors); the
+ *    library never owns parameters, gradients, inputs or outputs.  Workspaces (saved activations,
+ *    bf16 weight copies) belong to the context.
+ *  - kernels are enqueued on the caller's HIP stream (`stream`, a hipStream_t passed as void*); the
+ *    calls do not synchronise.  One host thread drives a context at a time (one process per GPU,
+ *    as the reference's mp.spawn launcher does, pretrain_videomae.py:509-513).
+ */
+#ifndef BVC_H
+#define BVC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BVC_OK 0
+#define BVC_ERR_INVALID (-1) /* bad argument / unsupported shape */
+#define BVC_ERR_HIP (-2)     /* a HIP runtime call failed */
+#define BVC_ERR_STATE (-3)   /* call order violated (e.g. backward without a matching forward) */
+
+const char* bvc_last_error(void);
+/* Library build info: "gfx950;<git-less build tag>" */
+const char* bvc_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * VideoMAE pre-training step.
+ * Replaces transformers.VideoMAEConfig as built by get_config(), pretrain_videomae.py:43-58.        */
+typedef struct bvc_videomae_config {
+    int image_size, patch_size, num_channels, num_frames, tubelet_size;
+    int hidden_size, num_hidden_layers, num_attention_heads, intermediate_size;
+    int decoder_hidden_size, decoder_num_hidden_layers, decoder_num_attention_heads, decoder_intermediate_size;
+    float layer_norm_eps;   /* 1e-12: every VideoMAELayer LayerNorm (HF:336-337) */
+    float decoder_norm_eps; /* 1e-5 : decoder.norm (HF:484) */
+    int norm_pix_loss;      /* 1 in the reference (pretrain_videomae.py:57) */
+} bvc_videomae_config;
+
+typedef struct bvc_ctx bvc_ctx;
+
+/* Flat parameter layout.  Parameters and gradients live in ONE contiguous fp32 buffer each (forward
+ * order: patch embed | encoder layers | encoder_to_decoder, mask_token | decoder layers | decoder.norm
+ * | decoder.head), so casts, the optimiser and the data-parallel all-reduce are single large
+ * transfers.  Entry `index` names a state-dict key of VideoMAEForPreTraining (the 264 keys that
+ * model.module.state_dict() returns at pretrain_videomae.py:76) and where it sits in the buffer. */
+int bvc_videomae_param_count(const bvc_videomae_config* cfg);
+int64_t bvc_videomae_param_numel(const bvc_videomae_config* cfg);
+int bvc_videomae_param_info(const bvc_videomae_config* cfg, int index, char* name, int name_cap, int64_t* offset,
+                            int64_t* numel, int* ndim, int64_t shape[5]);
+
+/* Allocates workspaces for up to `max_batch` clips with `num_masked` masked tokens per clip. */
+int bvc_videomae_create(const bvc_videomae_config* cfg, int max_batch, int num_masked, bvc_ctx** out);
+void bvc_videomae_destroy(bvc_ctx* ctx);
+
+/* Replaces `outputs = xmodel(inputs, bool_masked_pos=m); outputs.loss` (pretrain_videomae.py:301-302,
+ * i.e. VideoMAEForPreTraining.forward, HF:531-671).
+ *   pixels_dev  f32 [batch][num_frames][channels][H][W]   (loader output, homeview.py:218-231)
+ *   mask_dev    u8  [batch][seq_len], 1 = masked; every row must hold exactly num_masked ones
+ *   params_dev  f32 flat parameter buffer (layout above)
+ *   loss_dev    f32 scalar  (mean squared error over masked, per-patch-normalised pixels)
+ *   logits_dev  optional f32 [batch][num_masked][patch_dim] (outputs.logits), may be NULL
+ * A row with a different number of ones makes the loss NaN (flag checked on the device, no host sync). */
+int bvc_videomae_forward(bvc_ctx* ctx, const float* pixels_dev, const uint8_t* mask_dev, int batch,
+                         const float* params_dev, float* loss_dev, float* logits_dev, void* stream);
+
+/* Called on the host, from inside bvc_videomae_backward, after every kernel that finalises the
+ * gradient range [offset, offset+count) of the flat gradient buffer has been enqueued on `stream`.
+ * The data-parallel wrapper records an event there and starts the RCCL all-reduce of that range on
+ * its communication stream (what DistributedDataParallel's bucket hooks do at
+ * pretrain_videomae.py:180-181,312).  Ranges arrive tail-first (decoder head ... patch embed). */
+typedef void (*bvc_bucket_fn)(int64_t offset, int64_t count, void* user);
+
+/* Replaces autograd's backward of the step (scaler.scale(loss).backward(), pretrain_videomae.py:312).
+ *   grad_loss_dev f32 scalar on the device: d(objective)/d(loss) (GradScaler's scale)
+ *   grads_dev     f32 flat gradient buffer, OVERWRITTEN with d(objective)/d(param) */
+int bvc_videomae_backward(bvc_ctx* ctx, const float* grad_loss_dev, float* grads_dev, bvc_bucket_fn on_bucket,
+                          void* user, void* stream);
+
+/* Copies a saved activation of the last forward as f32 into dst_dev (parity probes: "embed",
+ * "enc<i>", "x_full", "dec<i>", "labels").  Returns the element count via *numel. */
+int bvc_videomae_tap(bvc_ctx* ctx, const char* name, float* dst_dev, int64_t capacity, int64_t* numel, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Operator-level entry points (the kernels the step is built from; also used by the parity tests). */
+enum { BVC_GEMM_NT = 0, BVC_GEMM_NN = 1, BVC_GEMM_TN = 2 };
+enum {
+    BVC_EPI_F32 = 0, BVC_EPI_BF16 = 1, BVC_EPI_GELU = 2, BVC_EPI_RESID = 3, BVC_EPI_POS = 4, BVC_EPI_E2D = 5,
+    BVC_EPI_LOSS = 6, BVC_EPI_DGELU = 7, BVC_EPI_F32_BF16 = 8
+};
+/* C[M,N] = epilogue(alpha * alpha_dev[0] * sum_k A(m,k) B(k,n)); bf16 operands, f32 accumulation.
+ * Replaces the nn.Linear forward / backward GEMMs that ATen dispatches for HF:225-237,269-275,299-322. */
+typedef struct bvc_gemm_desc {
+    const void* A; const void* B;   /* bf16 */
+    int M, N, K, lda, ldb;
+    uint32_t a_bytes, b_bytes;      /* extents of the A / B allocations (rows past them read as 0) */
+    float alpha;
+    const float* alpha_dev;         /* optional device scalar multiplied into alpha */
+    int epi, split_k;
+    void* C; int ldc; void* C2;
+    const float* bias; const float* resid; const void* aux; int ldaux;
+    const int* rowtok; const float* pos; const float* labels; float* partial;
+    int rin, rout;
+} bvc_gemm_desc;
+int bvc_op_gemm(const bvc_gemm_desc* problems, int count, int layout, int tile_cfg, void* stream);
+int bvc_op_gemm_num_tiles(const bvc_gemm_desc* problem, int tile_cfg);
+
+/* softmax(QK^T/8)V for head_dim 64; qkv bf16 [B*N][3*64*H]; replaces HF:181-206 / SDPA (HF:239-252) */
+int bvc_op_attention_fwd(const void* qkv, void* ctx_out, float* lse, int B, int N, int H, void* stream);
+int bvc_op_attention_bwd(const void* qkv, const void* ctx_in, const void* dctx, const float* lse, float* delta_scratch,
+                         void* dqkv, int B, int N, int H, void* stream);
+/* nn.LayerNorm forward/backward (HF:336-337,484); rows may be strided by (rin, rout, roff), rin<=0 = dense */
+int bvc_op_layernorm_fwd(const float* x, int rin, int rout, int roff, const float* gamma, const float* beta, void* y_bf16,
+                         float* mean, float* rstd, int M, int D, float eps, void* stream);
+int bvc_op_layernorm_bwd(const void* dy_bf16, const float* x, int rin, int rout, int roff, const float* mean,
+                         const float* rstd, const float* gamma, float* dres, int accumulate, void* dres_bf16,
+                         float* dgamma, float* dbeta, int M, int D, void* stream);
+int bvc_op_colsum_bf16(const void* X, int M, int N, int ld, float alpha, const float* alpha_dev, float* out, void* stream);
+int bvc_op_cast_bf16(const float* in, void* out, int64_t n, void* stream);
+/* boolean mask -> ascending visible / masked token lists (the order x[~mask] / x[mask] produce, HF:121,578-579) */
+int bvc_op_mask_index(const uint8_t* mask, int B, int L, int nvis, int nmask, int* vis_idx, int* msk_idx, int* status, void* stream);
+/* tube patches of the visible tokens in Conv3d weight order (HF:157-177) */
+int bvc_op_gather_patches(const float* clip, const int* vis_idx, void* A_bf16, int B, int nvis, int T, int C, int H, int W,
+                          int ts, int ps, void* stream);
+/* per-patch-normalised pixel targets of the masked tokens (HF:588-661) */
+int bvc_op_pixel_labels(const float* clip, const int* msk_idx, float* labels, int B, int nmask, int T, int C, int H, int W,
+                        int ts, int ps, int norm_pix, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BVC_H */

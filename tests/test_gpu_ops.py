@@ -1,0 +1,345 @@
+"""Per-kernel parity of libbvc_hip.so (through the C ABI) against plain fp32 torch on the same inputs.
+
+Floating-point kernels: bf16 MFMA operands with f32 accumulation, so the reference is an fp32
+product of the same bf16-rounded inputs; tolerances are written next to each check.
+Integer/index kernels (mask -> token lists, patch gather) are bit-exact.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+if not torch.cuda.is_available():   # collected on the CPU box, run on the GPU box
+    pytest.skip("needs a GPU", allow_module_level=True)
+
+from tests import gpu_util as G   # noqa: E402
+from oracle import videomae_oracle as vo   # noqa: E402
+
+L = G.L
+dev = "cuda"
+
+
+# --------------------------------------------------------------------------- GEMM
+def _ref_gemm(A, B, layout):
+    a, b = A.float(), B.float()
+    if layout == G.NT:
+        return a @ b.t()
+    if layout == G.NN:
+        return a @ b
+    return a.t() @ b
+
+
+def _shapes(layout, M, N, K):
+    # storage shapes of A and B for C[M,N] with contraction K
+    if layout == G.NT:
+        return (M, K), (N, K)
+    if layout == G.NN:
+        return (M, K), (K, N)
+    return (K, M), (K, N)
+
+
+@pytest.mark.parametrize("layout", [G.NT, G.NN, G.TN])
+@pytest.mark.parametrize("tile", [0, 1, 2])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (200, 192, 256), (160, 384, 64), (2560, 768, 768), (136, 72, 192)])
+def test_gemm_f32(layout, tile, M, N, K):
+    if layout == G.TN and M % 8:
+        M = (M // 8) * 8
+    sa, sb = _shapes(layout, M, N, K)
+    A = G.bf16_randn(*sa, seed=1)
+    B = G.bf16_randn(*sb, seed=2)
+    C = torch.full((M, N), float("nan"), device=dev)
+    G.run_gemm([G.gemm_desc(A, B, M, N, K, G.EPI["F32"], C)], layout, tile)
+    torch.cuda.synchronize()
+    ref = _ref_gemm(A, B, layout)
+    # identical bf16 inputs, f32 accumulation in a different order: 1e-5 relative is generous
+    assert G.rel_err(C, ref) < 1e-5, (layout, tile, M, N, K)
+    assert torch.isfinite(C).all()
+
+
+@pytest.mark.parametrize("K", [72, 200, 1000])
+def test_gemm_tn_ragged_contraction(K):
+    # weight-gradient product with a contraction length (tokens) that is not a multiple of 64:
+    # rows past the allocation must read as zero
+    M, N = 128, 192
+    A = G.bf16_randn(K, M, seed=3)
+    B = G.bf16_randn(K, N, seed=4)
+    C = torch.zeros(M, N, device=dev)
+    G.run_gemm([G.gemm_desc(A, B, M, N, K, G.EPI["F32"], C)], G.TN, -1)
+    torch.cuda.synchronize()
+    assert G.rel_err(C, _ref_gemm(A, B, G.TN)) < 1e-5
+
+
+@pytest.mark.parametrize("layout,split", [(G.TN, 4), (G.TN, 7), (G.NT, 3)])
+def test_gemm_split_k_accumulates(layout, split):
+    M, N, K = 256, 128, 1024
+    sa, sb = _shapes(layout, M, N, K)
+    A, B = G.bf16_randn(*sa, seed=5), G.bf16_randn(*sb, seed=6)
+    C0 = torch.randn(M, N, device=dev)
+    C = C0.clone()
+    G.run_gemm([G.gemm_desc(A, B, M, N, K, G.EPI["F32"], C, split_k=split, alpha=0.5)], layout, -1)
+    torch.cuda.synchronize()
+    assert G.rel_err(C, C0 + 0.5 * _ref_gemm(A, B, layout)) < 1e-5
+
+
+def test_gemm_grouped_four_problems():
+    # the four weight gradients of one transformer layer in one launch
+    Mtok, D, I = 320, 128, 256
+    dy, act = G.bf16_randn(Mtok, D, seed=7), G.bf16_randn(Mtok, I, seed=8)
+    dh, ln2 = G.bf16_randn(Mtok, I, seed=9), G.bf16_randn(Mtok, D, seed=10)
+    dqkv, ln1 = G.bf16_randn(Mtok, 3 * D, seed=11), G.bf16_randn(Mtok, D, seed=12)
+    outs = [torch.zeros(D, I, device=dev), torch.zeros(I, D, device=dev), torch.zeros(D, D, device=dev), torch.zeros(3 * D, D, device=dev)]
+    descs = [G.gemm_desc(dy, act, D, I, Mtok, G.EPI["F32"], outs[0]),
+             G.gemm_desc(dh, ln2, I, D, Mtok, G.EPI["F32"], outs[1]),
+             G.gemm_desc(dy, ln2, D, D, Mtok, G.EPI["F32"], outs[2]),
+             G.gemm_desc(dqkv, ln1, 3 * D, D, Mtok, G.EPI["F32"], outs[3], split_k=2)]
+    G.run_gemm(descs, G.TN, -1)
+    torch.cuda.synchronize()
+    refs = [dy.float().t() @ act.float(), dh.float().t() @ ln2.float(), dy.float().t() @ ln2.float(), dqkv.float().t() @ ln1.float()]
+    for o, r in zip(outs, refs):
+        assert G.rel_err(o, r) < 1e-5
+
+
+def test_gemm_epilogues():
+    M, N, K = 200, 256, 128
+    A, W = G.bf16_randn(M, K, seed=20), G.bf16_randn(N, K, seed=21, scale=0.1)
+    bias = torch.randn(N, device=dev)
+    acc = A.float() @ W.float().t()
+    # BF16 + bias: one bf16 rounding of the result
+    C = torch.zeros(M, N, device=dev, dtype=torch.bfloat16)
+    G.run_gemm([G.gemm_desc(A, W, M, N, K, G.EPI["BF16"], C, bias=bias)], G.NT)
+    assert G.rel_err(C.float(), acc + bias) < 4e-3
+    # GELU: pre-activation and exact-erf GELU, both bf16
+    pre = torch.zeros(M, N, device=dev, dtype=torch.bfloat16)
+    act = torch.zeros_like(pre)
+    G.run_gemm([G.gemm_desc(A, W, M, N, K, G.EPI["GELU"], pre, C2=act, bias=bias)], G.NT)
+    assert G.rel_err(pre.float(), acc + bias) < 4e-3
+    assert G.rel_err(act.float(), torch.nn.functional.gelu(acc + bias)) < 4e-3
+    # RESID out of place and in place
+    resid = torch.randn(M, N, device=dev)
+    out = torch.zeros(M, N, device=dev)
+    G.run_gemm([G.gemm_desc(A, W, M, N, K, G.EPI["RESID"], out, bias=bias, resid=resid)], G.NT)
+    assert G.rel_err(out, resid + acc + bias) < 1e-5
+    inpl = resid.clone()
+    G.run_gemm([G.gemm_desc(A, W, M, N, K, G.EPI["RESID"], inpl, bias=bias, resid=inpl, split_k=2)], G.NT)
+    assert G.rel_err(inpl, resid + acc + bias) < 1e-5
+    # POS: + pos[rowtok[m]]
+    tok = torch.randint(0, 50, (M,), device=dev, dtype=torch.int32)
+    pos = torch.randn(50, N, device=dev)
+    out = torch.zeros(M, N, device=dev)
+    G.run_gemm([G.gemm_desc(A, W, M, N, K, G.EPI["POS"], out, bias=bias, rowtok=tok, pos=pos)], G.NT)
+    assert G.rel_err(out, acc + bias + pos[tok.long()]) < 1e-5
+    # E2D: rows scattered to (m / rin) * rout + m % rin
+    rin, rout = 40, 100
+    big = torch.zeros(M // rin * rout, N, device=dev)
+    G.run_gemm([G.gemm_desc(A, W, M, N, K, G.EPI["E2D"], big, rowtok=tok, pos=pos, rin=rin, rout=rout)], G.NT)
+    ref = torch.zeros_like(big)
+    m = torch.arange(M, device=dev)
+    ref[(m // rin) * rout + m % rin] = acc + pos[tok.long()]
+    assert G.rel_err(big, ref) < 1e-5
+    # LOSS: diff (bf16), logits (f32), per-tile sum of squares
+    labels = torch.randn(M, N, device=dev)
+    diff = torch.zeros(M, N, device=dev, dtype=torch.bfloat16)
+    logits = torch.zeros(M, N, device=dev)
+    d = G.gemm_desc(A, W, M, N, K, G.EPI["LOSS"], diff, C2=logits, bias=bias, labels=labels)
+    nt = L.lib().bvc_op_gemm_num_tiles(d, -1)
+    partial = torch.zeros(nt, device=dev)
+    d.partial = partial.data_ptr()
+    G.run_gemm([d], G.NT)
+    assert G.rel_err(logits, acc + bias) < 1e-5
+    assert G.rel_err(diff.float(), acc + bias - labels) < 4e-3
+    assert abs(float(partial.sum()) - float(((acc + bias - labels) ** 2).sum())) / float(((acc + bias - labels) ** 2).sum()) < 1e-5
+    # DGELU (NN): dh = (dy W2) * gelu'(pre)
+    I = 256
+    dy, W2 = G.bf16_randn(M, N, seed=22), G.bf16_randn(N, I, seed=23, scale=0.1)
+    prei = G.bf16_randn(M, I, seed=24)
+    dh = torch.zeros(M, I, device=dev, dtype=torch.bfloat16)
+    G.run_gemm([G.gemm_desc(dy, W2, M, I, N, G.EPI["DGELU"], dh, aux=prei)], G.NN)
+    x = prei.float().requires_grad_(True)
+    torch.nn.functional.gelu(x).sum().backward()
+    assert G.rel_err(dh.float(), (dy.float() @ W2.float()) * x.grad) < 4e-3
+    # alpha from a device scalar + F32_BF16
+    s = torch.tensor([3.0], device=dev)
+    o32 = torch.zeros(M, N, device=dev)
+    o16 = torch.zeros(M, N, device=dev, dtype=torch.bfloat16)
+    G.run_gemm([G.gemm_desc(A, W, M, N, K, G.EPI["F32_BF16"], o32, C2=o16, alpha=0.5, alpha_dev=s)], G.NT)
+    assert G.rel_err(o32, 1.5 * acc) < 1e-5 and G.rel_err(o16.float(), 1.5 * acc) < 4e-3
+    torch.cuda.synchronize()
+
+
+# --------------------------------------------------------------------------- attention
+def _ref_attention(qkv, B, N, H):
+    D = 64 * H
+    x = qkv.float().view(B, N, 3, H, 64).permute(2, 0, 3, 1, 4)
+    q, k, v = x[0], x[1], x[2]
+    s = (q @ k.transpose(-1, -2)) * 0.125
+    p = torch.softmax(s, dim=-1)
+    o = (p @ v).transpose(1, 2).reshape(B * N, D)
+    lse2 = torch.logsumexp(s, dim=-1) * math.log2(math.e)
+    return o, lse2.reshape(B * H, N)
+
+
+@pytest.mark.parametrize("B,N,H", [(2, 160, 2), (1, 1568, 2), (3, 100, 1), (2, 24, 1), (1, 392, 3)])
+def test_attention_forward(B, N, H):
+    D = 64 * H
+    qkv = G.bf16_randn(B * N, 3 * D, seed=30)
+    ctx = torch.zeros(B * N, D, device=dev, dtype=torch.bfloat16)
+    lse = torch.zeros(B * H, N, device=dev)
+    L.check(L.lib().bvc_op_attention_fwd(G.ptr(qkv), G.ptr(ctx), G.ptr(lse), B, N, H, G.stream()), "attention_fwd")
+    torch.cuda.synchronize()
+    o, lse2 = _ref_attention(qkv, B, N, H)
+    # P is rounded to bf16 before P V and the output is bf16: 1e-2 relative L2
+    assert G.rel_err(ctx.float(), o) < 1e-2, G.rel_err(ctx.float(), o)
+    assert float((lse - lse2).abs().max()) < 2e-3
+
+
+@pytest.mark.parametrize("B,N,H", [(2, 160, 2), (1, 1568, 1), (3, 100, 1), (2, 24, 1)])
+def test_attention_backward(B, N, H):
+    D = 64 * H
+    qkv = G.bf16_randn(B * N, 3 * D, seed=31)
+    dctx = G.bf16_randn(B * N, D, seed=32)
+    ctx = torch.zeros(B * N, D, device=dev, dtype=torch.bfloat16)
+    lse = torch.zeros(B * H, N, device=dev)
+    L.check(L.lib().bvc_op_attention_fwd(G.ptr(qkv), G.ptr(ctx), G.ptr(lse), B, N, H, G.stream()), "attention_fwd")
+    dqkv = torch.full((B * N, 3 * D), float("nan"), device=dev, dtype=torch.bfloat16)
+    delta = torch.zeros(B * H, N, device=dev)
+    L.check(L.lib().bvc_op_attention_bwd(G.ptr(qkv), G.ptr(ctx), G.ptr(dctx), G.ptr(lse), G.ptr(delta), G.ptr(dqkv),
+                                         B, N, H, G.stream()), "attention_bwd")
+    torch.cuda.synchronize()
+    x = qkv.float().requires_grad_(True)
+    o, _ = _ref_attention(x, B, N, H)
+    (o * dctx.float()).sum().backward()
+    got, ref = dqkv.float(), x.grad
+    assert torch.isfinite(got).all()
+    for name, sl in (("dq", slice(0, D)), ("dk", slice(D, 2 * D)), ("dv", slice(2 * D, 3 * D))):
+        e = G.rel_err(got[:, sl], ref[:, sl])
+        assert e < 2e-2, (name, e)   # bf16 P / dS operands and bf16 outputs
+
+
+def test_attention_sharp_softmax():
+    # one key dominates each row: exercises the running-max update across key tiles
+    B, N, H = 1, 200, 1
+    g = torch.Generator().manual_seed(5)
+    q = torch.randn(N, 64, generator=g) * 4
+    k = torch.randn(N, 64, generator=g) * 4
+    v = torch.randn(N, 64, generator=g)
+    qkv = torch.cat([q, k, v], dim=1).to(torch.bfloat16).to(dev)
+    ctx = torch.zeros(N, 64, device=dev, dtype=torch.bfloat16)
+    lse = torch.zeros(1, N, device=dev)
+    L.check(L.lib().bvc_op_attention_fwd(G.ptr(qkv), G.ptr(ctx), G.ptr(lse), B, N, H, G.stream()), "attention_fwd")
+    torch.cuda.synchronize()
+    o, lse2 = _ref_attention(qkv, B, N, H)
+    assert G.rel_err(ctx.float(), o) < 1e-2
+    assert float(((lse - lse2).abs() / lse2.abs().clamp(min=1)).max()) < 1e-3
+
+
+# --------------------------------------------------------------------------- LayerNorm, column sums
+@pytest.mark.parametrize("M,D", [(160, 768), (1000, 384), (37, 128), (8, 64), (50, 1024)])
+def test_layernorm_forward_backward(M, D):
+    g = torch.Generator().manual_seed(40)
+    x = (torch.randn(M, D, generator=g) * 2 + 0.5).to(dev)
+    gamma = (1 + 0.1 * torch.randn(D, generator=g)).to(dev)
+    beta = (0.1 * torch.randn(D, generator=g)).to(dev)
+    y = torch.zeros(M, D, device=dev, dtype=torch.bfloat16)
+    mean, rstd = torch.zeros(M, device=dev), torch.zeros(M, device=dev)
+    L.check(L.lib().bvc_op_layernorm_fwd(G.ptr(x), 0, 0, 0, G.ptr(gamma), G.ptr(beta), G.ptr(y), G.ptr(mean), G.ptr(rstd),
+                                         M, D, 1e-12, G.stream()), "ln_fwd")
+    xr = x.clone().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(xr, (D,), gr, br, 1e-12)
+    assert G.rel_err(y.float(), ref) < 4e-3                     # one bf16 rounding
+    assert G.rel_err(mean, x.mean(1)) < 1e-5
+    dy = G.bf16_randn(M, D, seed=41)
+    dres0 = torch.randn(M, D, device=dev)
+    dres = dres0.clone()
+    dres_bf = torch.zeros(M, D, device=dev, dtype=torch.bfloat16)
+    dg, db = torch.zeros(D, device=dev), torch.zeros(D, device=dev)
+    L.check(L.lib().bvc_op_layernorm_bwd(G.ptr(dy), G.ptr(x), 0, 0, 0, G.ptr(mean), G.ptr(rstd), G.ptr(gamma), G.ptr(dres), 1,
+                                         G.ptr(dres_bf), G.ptr(dg), G.ptr(db), M, D, G.stream()), "ln_bwd")
+    torch.cuda.synchronize()
+    ref.backward(dy.float())
+    assert G.rel_err(dres - dres0, xr.grad) < 1e-4
+    assert G.rel_err(dres_bf.float(), dres) < 4e-3
+    assert G.rel_err(dg, gr.grad) < 1e-4 and G.rel_err(db, br.grad) < 1e-4
+
+
+def test_layernorm_row_map():
+    # "last nmask tokens of every clip": logical row m -> (m / rin) * rout + roff + m % rin
+    B, Lq, nm, D = 3, 20, 12, 128
+    x = torch.randn(B * Lq, D, device=dev)
+    gamma, beta = torch.ones(D, device=dev), torch.zeros(D, device=dev)
+    y = torch.zeros(B * nm, D, device=dev, dtype=torch.bfloat16)
+    mean, rstd = torch.zeros(B * nm, device=dev), torch.zeros(B * nm, device=dev)
+    L.check(L.lib().bvc_op_layernorm_fwd(G.ptr(x), nm, Lq, Lq - nm, G.ptr(gamma), G.ptr(beta), G.ptr(y), G.ptr(mean), G.ptr(rstd),
+                                         B * nm, D, 1e-5, G.stream()), "ln_fwd")
+    torch.cuda.synchronize()
+    ref = torch.nn.functional.layer_norm(x.view(B, Lq, D)[:, -nm:], (D,), eps=1e-5).reshape(B * nm, D)
+    assert G.rel_err(y.float(), ref) < 4e-3
+
+
+@pytest.mark.parametrize("M,N", [(2560, 768), (100, 3072), (25000, 384), (7, 64)])
+def test_colsum(M, N):
+    X = G.bf16_randn(M, N, seed=50)
+    out0 = torch.randn(N, device=dev)
+    out = out0.clone()
+    s = torch.tensor([2.0], device=dev)
+    L.check(L.lib().bvc_op_colsum_bf16(G.ptr(X), M, N, N, 0.25, G.ptr(s), G.ptr(out), G.stream()), "colsum")
+    torch.cuda.synchronize()
+    ref = out0 + 0.5 * X.float().sum(0)
+    assert float((out - ref).abs().max()) < 1e-3 * max(1.0, math.sqrt(M))
+
+
+# --------------------------------------------------------------------------- index / pixel kernels
+@pytest.mark.parametrize("cfg,B,ratio", [(vo.BASE, 3, 0.9), (vo.TINY, 4, 0.75)])
+def test_mask_index_gather_labels(cfg, B, ratio):
+    pixels, mask = vo.synthetic_batch(cfg, B, seed=3, mask_ratio=ratio)
+    Lq = cfg.seq_len
+    nmask = int(mask[0].sum())
+    nvis = Lq - nmask
+    px, mk = pixels.to(dev), mask.to(dev)
+    vis = torch.zeros(B * nvis, dtype=torch.int32, device=dev)
+    msk = torch.zeros(B * nmask, dtype=torch.int32, device=dev)
+    status = torch.zeros(4, dtype=torch.int32, device=dev)
+    L.check(L.lib().bvc_op_mask_index(G.ptr(mk), B, Lq, nvis, nmask, G.ptr(vis), G.ptr(msk), G.ptr(status), G.stream()), "mask_index")
+    torch.cuda.synchronize()
+    assert int(status[0]) == 0
+    # bit-exact: ascending token order, as x[~mask] / x[mask] enumerate them
+    for b in range(B):
+        assert torch.equal(vis[b * nvis:(b + 1) * nvis].cpu().long(), torch.nonzero(~mask[b]).flatten())
+        assert torch.equal(msk[b * nmask:(b + 1) * nmask].cpu().long(), torch.nonzero(mask[b]).flatten())
+    # a row with the wrong count raises the flag
+    bad = mk.clone()
+    bad[0, :] = True
+    L.check(L.lib().bvc_op_mask_index(G.ptr(bad), B, Lq, nvis, nmask, G.ptr(vis.clone()), G.ptr(msk.clone()), G.ptr(status), G.stream()), "mask_index")
+    torch.cuda.synchronize()
+    assert int(status[0]) == 1
+
+    # tube patches of the visible tokens in Conv3d weight order == unfold of the clip (exact up to the bf16 cast)
+    K = cfg.patch_dim
+    A = torch.zeros(B * nvis, K, device=dev, dtype=torch.bfloat16)
+    L.check(L.lib().bvc_op_gather_patches(G.ptr(px), G.ptr(vis), G.ptr(A), B, nvis, cfg.num_frames, cfg.num_channels,
+                                          cfg.image_size, cfg.image_size, cfg.tubelet_size, cfg.patch_size, G.stream()), "gather")
+    torch.cuda.synchronize()
+    ts, ps = cfg.tubelet_size, cfg.patch_size
+    T, C, H = cfg.num_frames, cfg.num_channels, cfg.image_size
+    v = pixels.permute(0, 2, 1, 3, 4).reshape(B, C, T // ts, ts, H // ps, ps, H // ps, ps)
+    v = v.permute(0, 2, 4, 6, 1, 3, 5, 7).reshape(B, Lq, K)       # token-major, (c, dt, dy, dx) inside
+    ref = v[~mask].reshape(B * nvis, K).to(torch.bfloat16)
+    assert torch.equal(A.cpu(), ref)
+
+    # pixel targets (HF:588-661) against the oracle's restatement
+    labels = torch.zeros(B * nmask, K, device=dev)
+    L.check(L.lib().bvc_op_pixel_labels(G.ptr(px), G.ptr(msk), G.ptr(labels), B, nmask, T, C, H, H, ts, ps, 1, G.stream()), "labels")
+    torch.cuda.synchronize()
+    ref = vo.pixel_labels(cfg, pixels, mask).reshape(B * nmask, K)
+    assert float((labels.cpu() - ref).abs().max()) < 2e-5
+
+
+def test_cast_bf16():
+    x = torch.randn(1000003, device=dev)
+    y = torch.zeros(1000003, device=dev, dtype=torch.bfloat16)
+    L.check(L.lib().bvc_op_cast_bf16(G.ptr(x), G.ptr(y), x.numel(), G.stream()), "cast")
+    torch.cuda.synchronize()
+    assert torch.equal(y, x.to(torch.bfloat16))   # round-to-nearest-even, bit-exact

@@ -1,0 +1,173 @@
+"""Headline benchmark: VideoMAE-base 16x224^2 pre-training clips/s on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One step = the reference's loop body (pretraining/generative/pretrain_videomae.py:292-317): host tube
+masks -> device, zero_grad, forward, loss all-reduce, GradScaler-scaled backward (with the bucketed RCCL
+gradient all-reduce overlapped when N > 1), scaler.step(SGD-Nesterov), scaler.update - on synthetic clips
+that are already resident in HBM.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as ge  # noqa: E402
+
+GFLOP_PER_CLIP = 202.295          # algorithmic fwd+bwd FLOPs per clip, BASELINE.md section 3
+PEAK_BF16_TFLOPS = 2500.0         # dense bf16 MFMA peak, MI355X_MICROARCH.md
+
+
+def synthetic_clips(batch, seed, device):
+    """uint8 ~ U{0..255} frames through the loader's transform (x/255 - 0.5)/0.25 (homeview.py:218-231)."""
+    g = torch.Generator().manual_seed(seed)
+    u8 = torch.randint(0, 256, (batch, 16, 3, 224, 224), generator=g, dtype=torch.uint8)
+    return ((u8.float() / 255.0 - 0.5) / 0.25).to(device)
+
+
+def host_cores():
+    """CPU threads this process may really use: affinity, capped by the cgroup quota and by the 16-core
+    share a one-GPU box grants (the box shows 256 logical CPUs; oversubscribing them stalls the oracle)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 16))
+
+
+def cpu_baseline(batch=4, steps=3):
+    """The oracle's fp32 CPU step (forward + backward + SGD-Nesterov) on a bounded sample of the same workload."""
+    from oracle import videomae_oracle as vo
+    torch.set_num_threads(host_cores())
+    cfg = vo.BASE
+    params = vo.make_params(cfg, seed=0, perturb=False)
+    pixels, mask = vo.synthetic_batch(cfg, batch, seed=1234, mask_ratio=0.9)
+    bufs = {}
+
+    def one():
+        _, grads = vo.step(cfg, params, pixels, mask)
+        vo.sgd_nesterov_step(params, grads, bufs, lr=0.1, momentum=0.9)
+
+    t0 = time.perf_counter()
+    one()
+    warm = time.perf_counter() - t0
+    if warm > 8.0:          # keep the default run within minutes on a slow host
+        steps = 1
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one()
+    dt = time.perf_counter() - t0
+    return {"value": round(batch * steps / dt, 3), "unit": "clips/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{steps} timed full steps (fwd+bwd+SGD) of VideoMAE-base at batch {batch}, fp32 torch CPU oracle, after 1 warm-up"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=16, help="clips per GPU (16 in the reference's slurm scripts)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)   # "nccl" is RCCL on ROCm
+
+    ge.build()
+    bvc = ge.load_package()
+    torch.manual_seed(0)
+    model = bvc.VideoMAEForPreTraining(bvc.VideoMAEConfig()).to(dev).train()
+    model._ensure_flat(dev)
+    xmodel = bvc.DistributedDataParallel(model, device_ids=[local_rank]) if world > 1 else model
+    opt = torch.optim.SGD(xmodel.parameters(), lr=0.1, momentum=0.9, nesterov=True, weight_decay=0.0)
+    scaler = torch.amp.GradScaler("cuda")
+    B = args.batch
+    clips = synthetic_clips(B, 1234 + rank, dev)
+    mask_gen = bvc.TubeMaskingGenerator((8, 14, 14), 0.9, rng=np.random.RandomState(1234 + rank))
+
+    def step():
+        bool_masked = np.zeros((B, 1568))
+        for i in range(B):
+            bool_masked[i, :] = mask_gen()
+        bool_masked_pos = torch.from_numpy(bool_masked).bool().to(dev)
+        opt.zero_grad()
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            out = xmodel(clips, bool_masked_pos=bool_masked_pos)
+            loss = bvc.AllReduce.apply(out.loss)
+        scaler.scale(loss).backward()
+        scaler.step(opt)
+        scaler.update()
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    fence()
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(args.steps):
+        loss = step()
+    e1.record()
+    fence()
+    dt = time.perf_counter() - t0
+    gpu_ms = e0.elapsed_time(e1)    # HIP events on the stream every kernel of the step is launched on
+    final_loss = float(loss.detach())
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t)
+
+    if rank == 0:
+        clips_s = world * B * args.steps / dt
+        step_ms_gpu = gpu_ms / args.steps
+        achieved = GFLOP_PER_CLIP * 1e9 * B / (step_ms_gpu * 1e-3) / 1e12
+        line = {
+            "metric": "video clips/sec (node) VideoMAE-base 16x224^2 bf16 pretraining",
+            "value": round(clips_s, 2), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "VideoMAE-base (ViT-B/16 encoder, 4-layer decoder), 16x224x224 clips, tubelet 2, 90% tube mask, "
+                                   "full training step (fwd + MSE + bwd + GradScaler + SGD-Nesterov)",
+                       "clips_per_gpu": B, "global_batch": world * B, "parallelism": f"dp{world}",
+                       "weights": "random init N(0,0.02), seed 0", "final_loss": round(final_loss, 5)},
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                         "kernel": "one training step = the fwd+bwd kernel sequence of libbvc_hip.so on the compute stream",
+                         "flops_per_launch": GFLOP_PER_CLIP * 1e9 * B, "launch_ms": round(step_ms_gpu, 4)},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

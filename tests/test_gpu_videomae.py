@@ -89,7 +89,9 @@ def _check_step(tag, cfg, B, seed, ratio, wseed=0, grad_scale=1.0, fixture=None)
         gn, rn = float(named[k].grad.norm()), float(ref_grads[k].norm())
         e = abs(gn - rn) / rn
         _log(f"[{tag}] grad-norm {k}: hip {gn:.6e} oracle {rn:.6e} rel {e:.2e}")
-        assert e < 1e-3 * 5, (k, e)   # TODO(tighten) target 1e-3
+        # north_star bar: 1e-3 relative.  The TINY model's probes average bf16 rounding noise over ~100x
+        # fewer elements than VideoMAE-base's, so it is given 2.5e-3.
+        assert e < (1e-3 if cfg.hidden_size >= 768 else 2.5e-3), (k, e)
         if fixture is not None:
             fn = fixture["grad_probes"][k] * grad_scale
             _log(f"[{tag}]   vs transformers fixture {fn:.6e} rel {abs(gn - fn) / fn:.2e}")
@@ -184,9 +186,16 @@ def test_training_loop_with_gradscaler_and_sgd():
             out = model(pixels.to(dev), bool_masked_pos=mask.to(dev))
             loss = bvc.AllReduce.apply(out.loss)
         scaler.scale(loss).backward()
+        # read the probes before the optimiser: torch's foreach SGD-Nesterov adds momentum*buf INTO .grad,
+        # so the reference's post-step grad_logger (pretrain_videomae.py:318) logs g + m*buf; here the
+        # scaled gradients themselves are compared
+        stats = bvc.grad_logger(model.named_parameters())
+        inv = 1.0 / scaler.get_scale()
+        stats.enc_first_layer *= inv
+        stats.enc_last_layer *= inv
+        stats.dec_last_layer *= inv
         scaler.step(opt)
         scaler.update()
-        stats = bvc.grad_logger(model.named_parameters())
         rl, rg = vo.step(cfg, ref, pixels, mask)
         vo.sgd_nesterov_step(ref, rg, bufs, lr=0.1, momentum=0.9)
         rel = abs(float(loss) - float(rl)) / float(rl)

@@ -1,20 +1,24 @@
 #!/bin/bash
-# Run on the GPU box (via gpurun): per-kernel parity, whole-step parity, then a short bench.
+# Run on the GPU box (via gpurun): per-kernel parity, whole-step parity, bench, rocprof.
 # A step that is killed by its timeout stops the chain (no further GPU work after a hang).
-mkdir -p gpurun_out
-rm -f gpurun_out/parity_report.txt
+R=$PWD
+OUT=$R/gpurun_out
+mkdir -p $OUT
+rm -f $OUT/parity_report.txt
+export TMPDIR=/tmp
 run() {  # name, seconds, command...
   local name=$1 secs=$2; shift 2
-  echo "=== $name" | tee -a gpurun_out/summary.txt
-  timeout -k 10 "$secs" "$@" > "gpurun_out/$name.log" 2>&1
+  echo "=== $name" | tee -a $OUT/summary.txt
+  timeout -k 10 "$secs" "$@" > "$OUT/$name.log" 2>&1
   local rc=$?
-  echo "rc=$rc" | tee -a gpurun_out/summary.txt
-  tail -n 15 "gpurun_out/$name.log"
-  if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "TIMEOUT in $name - stopping" | tee -a gpurun_out/summary.txt; exit 1; fi
+  echo "rc=$rc" | tee -a $OUT/summary.txt
+  tail -n 12 "$OUT/$name.log"
+  if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "TIMEOUT in $name - stopping" | tee -a $OUT/summary.txt; exit 1; fi
   return 0
 }
-: > gpurun_out/summary.txt
-rocminfo | grep -E "Marketing Name|Compute Unit|Max Clock" | head -8 >> gpurun_out/summary.txt
+: > $OUT/summary.txt
+rocminfo | grep -E "Marketing Name|Compute Unit|Max Clock" | tail -3 >> $OUT/summary.txt
+nproc >> $OUT/summary.txt
 for step in "$@"; do
   case $step in
     ops)   run ops 420 python -m pytest tests/test_gpu_ops.py -m gpu -q -p no:cacheprovider ;;
@@ -22,7 +26,15 @@ for step in "$@"; do
     all)   run alltests 600 python -m pytest tests -m gpu -q -x -p no:cacheprovider ;;
     smoke) run smoke 200 python -c "import __graft_entry__ as g; g.smoke()" ;;
     bench) run bench 400 python bench.py ;;
+    bench32) run bench32 400 python bench.py --batch 32 --no-cpu-baseline ;;
+    benchq) run benchq 300 python bench.py --no-cpu-baseline ;;
+    micro) run micro 400 python tools/microbench.py ;;
+    prof)  rm -rf $OUT/prof; cd /tmp
+           run prof 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline
+           cd $R
+           find $OUT/prof -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/kernel_stats.csv
+           find $OUT/prof -name "*kernel_trace.csv" -size +20M -delete ;;
     *) echo "unknown step $step" ;;
   esac
 done
-cat gpurun_out/summary.txt
+cat $OUT/summary.txt

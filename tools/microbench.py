@@ -1,0 +1,97 @@
+"""Per-kernel microbenchmarks of libbvc_hip.so at the VideoMAE-base shapes (batch 16): TFLOP/s or GB/s per launch,
+timed with HIP events on the launch stream.  Used to steer optimisation; numbers go to gpurun_out/micro.json."""
+import json
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from tests import gpu_util as G  # noqa: E402
+
+L = G.L
+dev = "cuda"
+
+
+def timeit(fn, iters=20, warm=3):
+    for _ in range(warm):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def gemm_case(name, layout, M, N, K, tile=-1, split=1, epi="BF16"):
+    if layout == G.NT:
+        A, B = G.bf16_randn(M, K), G.bf16_randn(N, K)
+    elif layout == G.NN:
+        A, B = G.bf16_randn(M, K), G.bf16_randn(K, N)
+    else:
+        A, B = G.bf16_randn(K, M), G.bf16_randn(K, N)
+    C = torch.zeros(M, N, device=dev, dtype=torch.float32 if epi == "F32" else torch.bfloat16)
+    d = G.gemm_desc(A, B, M, N, K, G.EPI[epi], C, split_k=split)
+    ms = timeit(lambda: G.run_gemm([d], layout, tile))
+    tf = 2.0 * M * N * K / (ms * 1e-3) / 1e12
+    return {"name": name, "layout": ["NT", "NN", "TN"][layout], "M": M, "N": N, "K": K, "tile": tile, "split": split,
+            "ms": round(ms, 4), "tflops": round(tf, 1)}
+
+
+def attn_case(B, N, H):
+    D = 64 * H
+    qkv = G.bf16_randn(B * N, 3 * D)
+    ctx = torch.zeros(B * N, D, device=dev, dtype=torch.bfloat16)
+    lse = torch.zeros(B * H, N, device=dev)
+    dctx = G.bf16_randn(B * N, D, seed=2)
+    dqkv = torch.zeros_like(qkv)
+    delta = torch.zeros(B * H, N, device=dev)
+    f = lambda: L.check(L.lib().bvc_op_attention_fwd(G.ptr(qkv), G.ptr(ctx), G.ptr(lse), B, N, H, G.stream()))
+    b = lambda: L.check(L.lib().bvc_op_attention_bwd(G.ptr(qkv), G.ptr(ctx), G.ptr(dctx), G.ptr(lse), G.ptr(delta), G.ptr(dqkv), B, N, H, G.stream()))
+    mf, mb = timeit(f), timeit(b)
+    flops = 4.0 * B * H * N * N * 64
+    return {"name": f"attn B{B} N{N} H{H}", "fwd_ms": round(mf, 4), "fwd_tflops": round(flops / (mf * 1e-3) / 1e12, 1),
+            "bwd_ms": round(mb, 4), "bwd_tflops_5prod": round(2.5 * flops / (mb * 1e-3) / 1e12, 1)}
+
+
+def main():
+    Bc = int(os.environ.get("BVC_BATCH", "16"))
+    Me, Md, Mm = Bc * 160, Bc * 1568, Bc * 1408
+    out = []
+    cases = [
+        ("enc qkv", G.NT, Me, 2304, 768), ("enc proj", G.NT, Me, 768, 768), ("enc fc1", G.NT, Me, 3072, 768), ("enc fc2", G.NT, Me, 768, 3072),
+        ("dec qkv", G.NT, Md, 1152, 384), ("dec proj", G.NT, Md, 384, 384), ("dec fc1", G.NT, Md, 1536, 384), ("dec fc2", G.NT, Md, 384, 1536),
+        ("head", G.NT, Mm, 1536, 384), ("patch", G.NT, Me, 768, 1536),
+        ("enc dX fc2", G.NN, Me, 3072, 768), ("enc dX fc1", G.NN, Me, 768, 3072), ("enc dX qkv", G.NN, Me, 768, 2304),
+        ("dec dX fc2", G.NN, Md, 1536, 384), ("dec dX fc1", G.NN, Md, 384, 1536), ("dec dX qkv", G.NN, Md, 384, 1152),
+        ("enc dW fc1", G.TN, 3072, 768, Me), ("enc dW qkv", G.TN, 2304, 768, Me), ("dec dW fc1", G.TN, 1536, 384, Md),
+        ("square 4096", G.NT, 4096, 4096, 4096), ("square 8192", G.NT, 8192, 8192, 8192),
+    ]
+    for name, lay, M, N, K in cases:
+        for tile in ((-1,) if "square" not in name else (0,)):
+            split = 1
+            epi = "F32" if lay == G.TN else "BF16"
+            if lay == G.TN and "dec" in name:
+                split = 5
+            r = gemm_case(name, lay, M, N, K, tile, split, epi)
+            out.append(r)
+            print(r, flush=True)
+    for tile in (0, 1, 2):
+        r = gemm_case(f"enc proj tile{tile}", G.NT, Me, 768, 768, tile)
+        out.append(r); print(r, flush=True)
+        r = gemm_case(f"dec fc1 tile{tile}", G.NT, Md, 1536, 384, tile)
+        out.append(r); print(r, flush=True)
+    for (B, N, H) in [(Bc, 160, 12), (Bc, 1568, 6)]:
+        r = attn_case(B, N, H)
+        out.append(r); print(r, flush=True)
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "micro.json"), "w") as f:
+        json.dump(out, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()

@@ -37,6 +37,7 @@ class DistributedDataParallel(nn.Module):
         self._comm_stream = None
         self._works = []
         self.reduced_ranges = []      # ranges all-reduced during the last backward (introspection / tests)
+        self._fresh = True
         self._device = None
         if device_ids:
             self._device = torch.device("cuda", device_ids[0]) if isinstance(device_ids[0], int) else torch.device(device_ids[0])
@@ -62,6 +63,8 @@ class DistributedDataParallel(nn.Module):
     def _on_range(self, offset, count):
         """Host callback from the library: gradients [offset, offset+count) are enqueued."""
         lo, hi = offset, offset + count
+        if self._fresh:
+            self.reduced_ranges, self._fresh = [], False
         if self._pending is None:
             self._pending = (lo, hi)
         else:
@@ -103,6 +106,4 @@ class DistributedDataParallel(nn.Module):
             self._pending = None
         if self._comm_stream is not None:
             torch.cuda.current_stream(self._comm_stream.device).wait_stream(self._comm_stream)
-
-    def begin_step(self):
-        self.reduced_ranges = []
+        self._fresh = True

@@ -15,3 +15,4 @@ from .mask import TubeMaskingGenerator, RandomMaskingGenerator  # noqa: F401
 from .ddp import DistributedDataParallel  # noqa: F401
 from .ddputils import AllReduce  # noqa: F401
 from .loggingtools import grad_logger  # noqa: F401
+from . import optim  # noqa: F401

@@ -35,6 +35,7 @@ class GemmDesc(ctypes.Structure):
         ("bias", c_void_p), ("resid", c_void_p), ("aux", c_void_p), ("ldaux", c_int),
         ("rowtok", c_void_p), ("pos", c_void_p), ("labels", c_void_p), ("partial", c_void_p),
         ("rin", c_int), ("rout", c_int),
+        ("rowsum", c_void_p),
     ]
 
 
@@ -54,16 +55,19 @@ SYMBOLS = {
     "bvc_videomae_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "bvc_videomae_backward": (c_int, [c_void_p, c_void_p, c_void_p, BUCKET_FN, c_void_p, c_void_p]),
     "bvc_videomae_tap": (c_int, [c_void_p, c_char_p, c_void_p, c_int64, ctypes.POINTER(c_int64), c_void_p]),
-    "bvc_op_gemm": (c_int, [ctypes.POINTER(GemmDesc), c_int, c_int, c_int, c_void_p]),
+    "bvc_op_gemm": (c_int, [ctypes.POINTER(GemmDesc), c_int, c_int, c_int, c_int, c_void_p]),
     "bvc_op_gemm_num_tiles": (c_int, [ctypes.POINTER(GemmDesc), c_int]),
     "bvc_op_attention_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "bvc_op_attention_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "bvc_op_layernorm_fwd": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_int, c_int, c_float, c_void_p]),
     "bvc_op_layernorm_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
-                                     c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+                                     c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "bvc_op_layernorm_bwd_workspace": (c_int64, [c_int, c_int]),
     "bvc_op_colsum_bf16": (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
     "bvc_op_cast_bf16": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "bvc_op_sgd_step": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_int, c_int, c_int,
+                                c_void_p, c_void_p, c_int, c_void_p]),
     "bvc_op_mask_index": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "bvc_op_gather_patches": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "bvc_op_pixel_labels": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),

@@ -31,7 +31,8 @@ constexpr int kMaxGroup = 4;
 
 // Launch 1..4 independent problems of the same layout as ONE grid (grouped GEMM) on `stream`.
 // tile_cfg: -1 = pick from the tile count; 0 = 128x128, 1 = 128x64, 2 = 64x64.
-int launch_gemm(const GemmProblem* probs, int nprob, GemmLayout layout, int tile_cfg, hipStream_t stream);
+// stages: -1 = pick from the grid size; 2..4 = LDS ring depth (K-steps of LDS-DMA in flight + 1).
+int launch_gemm(const GemmProblem* probs, int nprob, GemmLayout layout, int tile_cfg, hipStream_t stream, int stages = -1);
 
 // number of loss partials an EPI_LOSS problem writes with the tile config launch_gemm would pick
 int gemm_num_tiles(const GemmProblem& p, int tile_cfg);

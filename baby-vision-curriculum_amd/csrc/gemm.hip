@@ -92,13 +92,20 @@ __device__ __forceinline__ bf16x8 read_frag(const char* lds, int rbase, int ks, 
     }
 }
 
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
 // ------------------------------------------------------------------ the kernel
-template <int BM, int BN, bool AT, bool BT>
+// NS = LDS ring depth.  NS-1 K-steps of LDS-DMA are in flight while one is being multiplied; the
+// loop waits with a COUNTED vmcnt (never 0 except at the tail) and a raw s_barrier, so the DMA of
+// later stages keeps flying across the barrier (a __syncthreads() would drain it).
+template <int BM, int BN, bool AT, bool BT, int NS>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmGroup g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int BK = 64;
     constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
     constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 16, TN = WN / 16;
+    constexpr int DMA_PER_STAGE = BM / 32 + BN / 32;   // LDS-DMA instructions per wave per stage
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -135,21 +142,39 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmGroup g) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    if (nt > 0) {
-        stage_tile<BM, AT>(ra, m0, t0 * BK, p.lda, smem, wave, lane);
-        stage_tile<BN, BT>(rb, n0, t0 * BK, p.ldb, smem + A_BYTES, wave, lane);
-    }
-    for (int it = 0; it < nt; ++it) {
-        // every wave drains its own DMA, then the barrier publishes the whole tile; the same barrier
-        // proves all waves are done reading the other stage (they read it before arriving here)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (it + 1 < nt) {
-            char* nxt = smem + ((it + 1) & 1) * STAGE;
-            stage_tile<BM, AT>(ra, m0, (t0 + it + 1) * BK, p.lda, nxt, wave, lane);
-            stage_tile<BN, BT>(rb, n0, (t0 + it + 1) * BK, p.ldb, nxt + A_BYTES, wave, lane);
+    // bias gradient fused into the weight-gradient product: db[m] = sum_k A(m,k) is one more MFMA
+    // column against an all-ones operand, computed by the workgroups of the first column tile only
+    const bool do_rowsum = AT && p.rowsum != nullptr && n0 == 0 && wn == 0;
+    f32x4 accb[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (short)0x3F80;
+
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s) {
+        if (s < nt) {
+            stage_tile<BM, AT>(ra, m0, (t0 + s) * BK, p.lda, smem + s * STAGE, wave, lane);
+            stage_tile<BN, BT>(rb, n0, (t0 + s) * BK, p.ldb, smem + s * STAGE + A_BYTES, wave, lane);
         }
-        const char* la = smem + (it & 1) * STAGE;
+    }
+    int slot = 0, fill = NS - 1;   // slot being multiplied / slot the next DMA goes to
+    for (int it = 0; it < nt; ++it) {
+        // Stage `it` must have landed: all but the youngest min(NS-2, remaining) stages' DMAs are done.
+        const int rem = nt - 1 - it;
+        if (NS >= 4 && rem >= 2) wait_vmcnt<2 * DMA_PER_STAGE>();
+        else if (NS >= 3 && rem >= 1) wait_vmcnt<DMA_PER_STAGE>();
+        else wait_vmcnt<0>();
+        // own LDS reads of the previous step retired, then the barrier: publishes stage `it` from every
+        // wave and proves every wave is done reading the slot that is refilled next
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (it + NS - 1 < nt) {
+            char* nxt = smem + fill * STAGE;
+            stage_tile<BM, AT>(ra, m0, (t0 + it + NS - 1) * BK, p.lda, nxt, wave, lane);
+            stage_tile<BN, BT>(rb, n0, (t0 + it + NS - 1) * BK, p.ldb, nxt + A_BYTES, wave, lane);
+        }
+        const char* la = smem + slot * STAGE;
         const char* lb = la + A_BYTES;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -164,8 +189,15 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmGroup g) {
                 for (int j = 0; j < TN; ++j)
                     // operands swapped: D = Bfrag^T-view x Afrag gives lane (l&15) = m, regs = 4 consecutive n
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+            if (do_rowsum) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[i], accb[i], 0, 0, 0);
+            }
         }
+        slot = slot + 1 == NS ? 0 : slot + 1;
+        fill = fill + 1 == NS ? 0 : fill + 1;
     }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // LDS is reused by the loss epilogue
 
     // ------------------------------------------------------------------ epilogue
     const int epi = p.epi;
@@ -251,10 +283,16 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmGroup g) {
             }
         }
     }
+    if (do_rowsum && nt > 0 && (lane >> 4) == 0) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = m0 + wm * WM + 16 * i + lane;
+            if (m < p.M) atomicAdd(p.rowsum + m, accb[i][0] * alpha);
+        }
+    }
     if (epi == EPI_LOSS) {   // uniform per workgroup: deterministic per-tile partial of sum (logit-label)^2
         float* red = reinterpret_cast<float*>(smem);
         const float w = wave_sum(sumsq);
-        __syncthreads();
         if (lane == 0) red[wave] = w;
         __syncthreads();
         if (tid == 0) p.partial[tile] = (red[0] + red[1]) + (red[2] + red[3]);
@@ -275,31 +313,65 @@ static int tiles_for(const GemmProblem& p, int cfg) {
 
 int gemm_pick_tile(const GemmProblem* probs, int nprob, int tile_cfg) {
     if (tile_cfg >= 0) return tile_cfg;
-    // 256 CUs, 2+ workgroups per CU resident: prefer the big tile once it alone fills the chip
-    for (int cfg = 0; cfg < 2; ++cfg) {
-        int t = 0;
-        for (int i = 0; i < nprob; ++i) t += tiles_for(probs[i], cfg) * probs[i].split_k;
-        if (t >= (cfg == 0 ? 300 : 200)) return cfg;
+    // Measured on MI355X (profiles/r01_b_microbench.json): a workgroup's speed is set by its L2->LDS fill
+    // rate (~70 GB/s per CU), so the big tile (64 FLOP/B) wins once it alone covers the 256 CUs ~1.5x;
+    // below that, more and smaller workgroups win.  Narrow outputs (N <= 384) prefer 128x64 (3 workgroups/CU).
+    int t0 = 0, t1 = 0, nmax = 0;
+    for (int i = 0; i < nprob; ++i) {
+        t0 += tiles_for(probs[i], 0) * probs[i].split_k;
+        t1 += tiles_for(probs[i], 1) * probs[i].split_k;
+        nmax = probs[i].N > nmax ? probs[i].N : nmax;
     }
+    if (nmax <= 384) return t1 >= 256 ? 1 : 2;
+    if (t0 >= 400) return 0;
+    if (t1 >= 400) return 1;
     return 2;
 }
 
 int gemm_num_tiles(const GemmProblem& p, int tile_cfg) { return tiles_for(p, gemm_pick_tile(&p, 1, tile_cfg)); }
 
-template <int BM, int BN>
-static int launch_cfg(const GemmGroup& g, GemmLayout layout, int nblocks, hipStream_t stream) {
-    const size_t lds = 2 * (BM + BN) * 64 * 2;
-    switch (layout) {
-        case GEMM_NT: hipLaunchKernelGGL((gemm_kernel<BM, BN, false, false>), dim3(nblocks), dim3(256), lds, stream, g); break;
-        case GEMM_NN: hipLaunchKernelGGL((gemm_kernel<BM, BN, false, true>), dim3(nblocks), dim3(256), lds, stream, g); break;
-        case GEMM_TN: hipLaunchKernelGGL((gemm_kernel<BM, BN, true, true>), dim3(nblocks), dim3(256), lds, stream, g); break;
-        default: set_error("launch_gemm: bad layout %d", (int)layout); return BVC_ERR_INVALID;
+template <int BM, int BN, bool AT, bool BT, int NS>
+static int launch_one(const GemmGroup& g, int nblocks, hipStream_t stream) {
+    constexpr size_t lds = (size_t)NS * (BM + BN) * 64 * 2;
+    static bool attr_set = false;   // > 64 KiB of dynamic LDS needs the attribute once per kernel
+    if (lds > 65536 && !attr_set) {
+        BVC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<BM, BN, AT, BT, NS>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
     }
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, AT, BT, NS>), dim3(nblocks), dim3(256), lds, stream, g);
     BVC_CHECK_HIP(hipGetLastError());
     return BVC_OK;
 }
 
-int launch_gemm(const GemmProblem* probs, int nprob, GemmLayout layout, int tile_cfg, hipStream_t stream) {
+template <int BM, int BN, int NS>
+static int launch_cfg(const GemmGroup& g, GemmLayout layout, int nblocks, hipStream_t stream) {
+    switch (layout) {
+        case GEMM_NT: return launch_one<BM, BN, false, false, NS>(g, nblocks, stream);
+        case GEMM_NN: return launch_one<BM, BN, false, true, NS>(g, nblocks, stream);
+        case GEMM_TN: return launch_one<BM, BN, true, true, NS>(g, nblocks, stream);
+        default: set_error("launch_gemm: bad layout %d", (int)layout); return BVC_ERR_INVALID;
+    }
+}
+
+template <int BM, int BN>
+static int launch_stages(const GemmGroup& g, GemmLayout layout, int stages, int nblocks, hipStream_t stream) {
+    switch (stages) {
+        case 2: return launch_cfg<BM, BN, 2>(g, layout, nblocks, stream);
+        case 3: return launch_cfg<BM, BN, 3>(g, layout, nblocks, stream);
+        default: return launch_cfg<BM, BN, 4>(g, layout, nblocks, stream);
+    }
+}
+
+// ring depth.  Measured: a third stage only pays for long-K k-contiguous products on the small tile
+// (enc fc2, K = 3072: 27 -> 23 us); everywhere else it costs a resident workgroup per CU and loses.
+int gemm_pick_stages(int cfg, GemmLayout layout, int kmax, int stages) {
+    if (stages >= 2 && stages <= 4) return stages;
+    if (layout == GEMM_NT && cfg == 2 && kmax >= 2048) return 3;
+    return 2;
+}
+
+int launch_gemm(const GemmProblem* probs, int nprob, GemmLayout layout, int tile_cfg, hipStream_t stream, int stages) {
     BVC_REQUIRE(nprob >= 1 && nprob <= kMaxGroup, "launch_gemm: nprob %d out of range", nprob);
     const int cfg = gemm_pick_tile(probs, nprob, tile_cfg);
     GemmGroup g;
@@ -313,6 +385,7 @@ int launch_gemm(const GemmProblem* probs, int nprob, GemmLayout layout, int tile
         if (layout != GEMM_TN) BVC_REQUIRE(p.K % 64 == 0, "launch_gemm: K=%d must be a multiple of 64 for k-contiguous operands", p.K);
         if (layout == GEMM_TN) BVC_REQUIRE(p.M % 8 == 0, "launch_gemm: TN needs M %% 8 == 0 (M=%d)", p.M);
         BVC_REQUIRE(p.split_k >= 1, "launch_gemm: split_k must be >= 1");
+        if (p.rowsum) BVC_REQUIRE(layout == GEMM_TN, "launch_gemm: rowsum (bias gradient) is fused into TN products only");
         if (p.split_k > 1)
             BVC_REQUIRE(p.epi == EPI_F32 || (p.epi == EPI_RESID && p.resid == p.C),
                         "launch_gemm: split_k needs an accumulating f32 epilogue");
@@ -322,10 +395,13 @@ int launch_gemm(const GemmProblem* probs, int nprob, GemmLayout layout, int tile
     }
     g.tile_start[nprob] = total;
     for (int i = nprob; i < kMaxGroup; ++i) { g.prob[i] = probs[0]; g.tile_start[i + 1] = total; }
+    int kmax = 0;
+    for (int i = 0; i < nprob; ++i) kmax = probs[i].K > kmax ? probs[i].K : kmax;
+    const int ns = gemm_pick_stages(cfg, layout, kmax, stages);
     switch (cfg) {
-        case 0: return launch_cfg<128, 128>(g, layout, total, stream);
-        case 1: return launch_cfg<128, 64>(g, layout, total, stream);
-        default: return launch_cfg<64, 64>(g, layout, total, stream);
+        case 0: return launch_stages<128, 128>(g, layout, ns, total, stream);
+        case 1: return launch_stages<128, 64>(g, layout, ns, total, stream);
+        default: return launch_stages<64, 64>(g, layout, ns, total, stream);
     }
 }
 

@@ -14,8 +14,11 @@ struct PatchGeom { int T, C, H, W, ts, ps; };
 
 int launch_ln_fwd(const float* x, RowMap rm, const float* gamma, const float* beta, bf16_t* y, float* mean, float* rstd,
                   int M, int D, float eps, hipStream_t s);
+// `part` = scratch of ln_bwd_workspace_floats(M, D) floats (per-workgroup dgamma / dbeta partials)
+size_t ln_bwd_workspace_floats(int M, int D);
+size_t ln_bwd_workspace_floats_upto(int Mmax, int D);
 int launch_ln_bwd(const bf16_t* dy, const float* x, RowMap rm, const float* mean, const float* rstd, const float* gamma,
-                  float* dres, int accumulate, bf16_t* dres_bf, float* dgamma, float* dbeta, int M, int D, hipStream_t s);
+                  float* dres, int accumulate, bf16_t* dres_bf, float* dgamma, float* dbeta, float* part, int M, int D, hipStream_t s);
 int launch_colsum_bf16(const bf16_t* X, int M, int N, int ld, float alpha, float* out, hipStream_t s);
 int launch_colsum_bf16_scaled(const bf16_t* X, int M, int N, int ld, float alpha, const float* alpha_dev, float* out, hipStream_t s);
 int launch_colsum_f32(const float* X, RowMap rm, int M, int D, float* out, hipStream_t s);
@@ -26,6 +29,8 @@ int launch_gather_patches(const float* clip, const int* vis_idx, bf16_t* A, int 
 int launch_labels(const float* clip, const int* msk_idx, float* labels, int B, int nmask, PatchGeom pg, int norm_pix, hipStream_t s);
 int launch_fill_masked(float* xfull, const float* mask_token, const float* pos, const int* msk_idx, int B, int L, int nvis,
                        int nmask, int D, hipStream_t s);
+int launch_sgd_step(float* p, float* g, float* buf, size_t n, float lr, float momentum, float dampening, float wd, int nesterov,
+                    int first, int maximize, const float* grad_scale, const float* found_inf, int write_grad, hipStream_t s);
 int launch_loss_finalize(const float* partial, int n, double count, const int* status, float* loss, hipStream_t s);
 
 }  // namespace bvc

@@ -56,13 +56,15 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 
 // ============================================================================ LayerNorm backward
 // dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma;  dres (+)= dx; optional bf16 copy;
-// dgamma += sum_rows dy * xhat, dbeta += sum_rows dy  (block-reduced, then one atomicAdd per column)
+// per-workgroup partials of dgamma = sum_rows dy * xhat and dbeta = sum_rows dy go to part[block][2][D]
+// (every workgroup hammering the same D addresses with atomics serialises: measured 2x on the kernel);
+// ln_param_reduce_kernel folds them into the gradients
 template <int RPB>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ dy, const float* __restrict__ x, RowMap rm,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ gamma, float* __restrict__ dres,
-                                                     int accumulate, bf16_t* __restrict__ dres_bf, float* __restrict__ dgamma,
-                                                     float* __restrict__ dbeta, int M, int D) {
+                                                     int accumulate, bf16_t* __restrict__ dres_bf, float* __restrict__ part,
+                                                     int M, int D) {
     __shared__ float red[4][2][kMaxChunks * 256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nch = D >> 2;
@@ -124,12 +126,26 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
         }
     }
     __syncthreads();
+    float* pg = part + (size_t)blockIdx.x * 2 * D;
     for (int col = threadIdx.x; col < D; col += 256) {
-        const float a = (red[0][0][col] + red[1][0][col]) + (red[2][0][col] + red[3][0][col]);
-        const float b = (red[0][1][col] + red[1][1][col]) + (red[2][1][col] + red[3][1][col]);
-        atomicAdd(dgamma + col, a);
-        atomicAdd(dbeta + col, b);
+        pg[col] = (red[0][0][col] + red[1][0][col]) + (red[2][0][col] + red[3][0][col]);
+        pg[D + col] = (red[0][1][col] + red[1][1][col]) + (red[2][1][col] + red[3][1][col]);
     }
+}
+
+// dgamma[c] += sum_b part[b][0][c], dbeta[c] += sum_b part[b][1][c]; grid (ceil(2D/256), ceil(nblk/16))
+__global__ __launch_bounds__(256) void ln_param_reduce_kernel(const float* __restrict__ part, int nblk, int D,
+                                                              float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= 2 * D) return;
+    const int b0 = blockIdx.y * 16, b1 = min(nblk, b0 + 16);
+    float v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = b0 + i < b1 ? part[(size_t)(b0 + i) * 2 * D + c] : 0.f;   // 16 loads in flight
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += v[i];
+    atomicAdd(c < D ? dgamma + c : dbeta + (c - D), s);
 }
 
 // ============================================================================ column sums
@@ -313,6 +329,50 @@ __global__ __launch_bounds__(256) void loss_finalize_kernel(const float* __restr
     if (threadIdx.x == 0) *loss = (status && *status) ? __int_as_float(0x7fc00000) : (float)(red[0] / count);
 }
 
+// ============================================================================ fused SGD (momentum / Nesterov)
+// torch.optim.SGD semantics (pretrain_videomae.py:187-189) over a flat range, one pass:
+//   g = grad / grad_scale (+ wd * p);  buf = first ? g : m * buf + (1 - damp) * g;  d = nesterov ? g + m * buf : buf;
+//   p -= lr * d;   the unscaled gradient is written back (what grad_logger reads after scaler.step).
+// Skips everything when *found_inf != 0 (GradScaler's contract for optimisers with _step_supports_amp_scaling).
+__global__ void sgd_step_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ buf, size_t n, float lr,
+                                float momentum, float dampening, float wd, int nesterov, int first, int maximize,
+                                const float* __restrict__ grad_scale, const float* __restrict__ found_inf, int write_grad) {
+    if (found_inf && *found_inf != 0.f) return;
+    const float inv = grad_scale ? 1.f / *grad_scale : 1.f;
+    const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i >= n) return;
+    if (i + 4 <= n) {
+        f32x4 pv = *reinterpret_cast<f32x4*>(p + i);
+        f32x4 gv = *reinterpret_cast<f32x4*>(g + i) * inv;
+        if (maximize) gv = -gv;
+        const f32x4 gu = gv;
+        if (wd != 0.f) gv += pv * wd;
+        f32x4 d = gv;
+        if (momentum != 0.f) {
+            f32x4 bv = first ? gv : *reinterpret_cast<f32x4*>(buf + i) * momentum + gv * (1.f - dampening);
+            *reinterpret_cast<f32x4*>(buf + i) = bv;
+            d = nesterov ? gv + bv * momentum : bv;
+        }
+        *reinterpret_cast<f32x4*>(p + i) = pv - d * lr;
+        if (write_grad) *reinterpret_cast<f32x4*>(g + i) = gu;
+    } else {
+        for (size_t j = i; j < n; ++j) {
+            float gv = g[j] * inv;
+            if (maximize) gv = -gv;
+            const float gu = gv;
+            if (wd != 0.f) gv += p[j] * wd;
+            float d = gv;
+            if (momentum != 0.f) {
+                const float bv = first ? gv : buf[j] * momentum + gv * (1.f - dampening);
+                buf[j] = bv;
+                d = nesterov ? gv + bv * momentum : bv;
+            }
+            p[j] -= lr * d;
+            if (write_grad) g[j] = gu;
+        }
+    }
+}
+
 // ============================================================================ launchers
 static inline unsigned blocks_for(size_t items, int per = 256) { return (unsigned)((items + per - 1) / per); }
 
@@ -324,13 +384,33 @@ int launch_ln_fwd(const float* x, RowMap rm, const float* gamma, const float* be
     return BVC_OK;
 }
 
+static inline int ln_bwd_rows_per_block(int M) { return M >= 16384 ? 16 : 4; }
+
+size_t ln_bwd_workspace_floats(int M, int D) {
+    const int rpb = ln_bwd_rows_per_block(M);
+    return (size_t)((M + rpb - 1) / rpb) * 2 * D;
+}
+
+// enough for every row count m <= Mmax (the rows-per-workgroup choice is not monotonic in m)
+size_t ln_bwd_workspace_floats_upto(int Mmax, int D) {
+    const size_t small = ln_bwd_workspace_floats(Mmax < 16383 ? Mmax : 16383, D);
+    const size_t big = ln_bwd_workspace_floats(Mmax, D);
+    return small > big ? small : big;
+}
+
 int launch_ln_bwd(const bf16_t* dy, const float* x, RowMap rm, const float* mean, const float* rstd, const float* gamma,
-                  float* dres, int accumulate, bf16_t* dres_bf, float* dgamma, float* dbeta, int M, int D, hipStream_t s) {
+                  float* dres, int accumulate, bf16_t* dres_bf, float* dgamma, float* dbeta, float* part, int M, int D, hipStream_t s) {
     BVC_REQUIRE(D % 4 == 0 && D <= kMaxChunks * 256, "ln_bwd: D=%d unsupported", D);
-    if (M >= 16384)
-        hipLaunchKernelGGL(ln_bwd_kernel<64>, dim3((M + 63) / 64), dim3(256), 0, s, dy, x, rm, mean, rstd, gamma, dres, accumulate, dres_bf, dgamma, dbeta, M, D);
+    BVC_REQUIRE(part != nullptr, "ln_bwd: workspace missing");
+    // rows per workgroup: enough workgroups to keep >= 16 waves per CU streaming (the kernel is HBM-bound and
+    // each wave walks its rows serially), few enough that the per-column atomics stay negligible
+    const int rpb = ln_bwd_rows_per_block(M);
+    const int nblk = (M + rpb - 1) / rpb;
+    if (rpb == 16)
+        hipLaunchKernelGGL(ln_bwd_kernel<16>, dim3(nblk), dim3(256), 0, s, dy, x, rm, mean, rstd, gamma, dres, accumulate, dres_bf, part, M, D);
     else
-        hipLaunchKernelGGL(ln_bwd_kernel<16>, dim3((M + 15) / 16), dim3(256), 0, s, dy, x, rm, mean, rstd, gamma, dres, accumulate, dres_bf, dgamma, dbeta, M, D);
+        hipLaunchKernelGGL(ln_bwd_kernel<4>, dim3(nblk), dim3(256), 0, s, dy, x, rm, mean, rstd, gamma, dres, accumulate, dres_bf, part, M, D);
+    hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * D + 255) / 256, (nblk + 15) / 16), dim3(256), 0, s, part, nblk, D, dgamma, dbeta);
     BVC_CHECK_HIP(hipGetLastError());
     return BVC_OK;
 }
@@ -393,6 +473,18 @@ int launch_labels(const float* clip, const int* msk_idx, float* labels, int B, i
 int launch_fill_masked(float* xfull, const float* mask_token, const float* pos, const int* msk_idx, int B, int L, int nvis,
                        int nmask, int D, hipStream_t s) {
     hipLaunchKernelGGL(fill_masked_kernel, dim3(blocks_for((size_t)B * nmask * (D / 4))), dim3(256), 0, s, xfull, mask_token, pos, msk_idx, B, L, nvis, nmask, D);
+    BVC_CHECK_HIP(hipGetLastError());
+    return BVC_OK;
+}
+
+int launch_sgd_step(float* p, float* g, float* buf, size_t n, float lr, float momentum, float dampening, float wd, int nesterov,
+                    int first, int maximize, const float* grad_scale, const float* found_inf, int write_grad, hipStream_t s) {
+    BVC_REQUIRE(momentum == 0.f || buf != nullptr, "sgd_step: momentum needs a buffer");
+    BVC_REQUIRE(((uintptr_t)p % 16 == 0) && ((uintptr_t)g % 16 == 0) && (buf == nullptr || (uintptr_t)buf % 16 == 0),
+                "sgd_step: buffers must be 16-byte aligned");
+    if (n == 0) return BVC_OK;
+    hipLaunchKernelGGL(sgd_step_kernel, dim3(blocks_for((n + 3) / 4)), dim3(256), 0, s, p, g, buf, n, lr, momentum, dampening, wd,
+                       nesterov, first, maximize, grad_scale, found_inf, write_grad);
     BVC_CHECK_HIP(hipGetLastError());
     return BVC_OK;
 }

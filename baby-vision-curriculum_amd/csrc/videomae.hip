@@ -179,6 +179,7 @@ struct bvc_ctx {
     float *dres_enc, *dres_dec;
     bf16_t *dyb, *dhb, *dln, *dctx, *dqkv, *dh, *de2d;
     float* delta;
+    float* ln_part;    // per-workgroup LayerNorm parameter-gradient partials
 };
 
 namespace {
@@ -233,17 +234,23 @@ GemmProblem gemm(const bf16_t* A, size_t a_elems, int lda, const bf16_t* B, size
     return p;
 }
 
-// split-K factor for a group of weight-gradient products: aim for >= ~2 workgroups per CU
-void set_split(GemmProblem* g, int n) {
-    int tiles = 0;
-    for (int i = 0; i < n; ++i) tiles += ((g[i].M + 127) / 128) * ((g[i].N + 127) / 128);
-    if (tiles >= 256) return;
+// Tile and split-K choice for a group of weight-gradient products (contraction over all tokens).
+// Measured (profiles/r01_b_microbench.json): when the 128x128 tiles alone cover the chip (encoder layer: 432)
+// use them unsplit; otherwise 64x64 tiles with just enough K-splits for ~850 workgroups (decoder layer: 432 x 2).
+int plan_dw(GemmProblem* g, int n) {
+    int t128 = 0, t64 = 0;
+    for (int i = 0; i < n; ++i) {
+        t128 += ((g[i].M + 127) / 128) * ((g[i].N + 127) / 128);
+        t64 += ((g[i].M + 63) / 64) * ((g[i].N + 63) / 64);
+    }
+    if (t128 >= 400) return 0;
     for (int i = 0; i < n; ++i) {
         const int ksteps = (g[i].K + 63) / 64;
-        int s = (512 + tiles - 1) / tiles;
-        s = std::min(s, std::max(1, ksteps / 8));
+        int s = (864 + t64 / 2) / t64;
+        s = std::min(s, std::max(1, ksteps / 16));
         g[i].split_k = std::max(1, s);
     }
+    return 2;
 }
 
 int layer_forward(bvc_ctx* c, Stack& s, int li, const LayerOff& o, float* x_in_external, float* x_out, int B, int N, hipStream_t st) {
@@ -295,7 +302,7 @@ int layer_backward(bvc_ctx* c, Stack& s, int li, const LayerOff& o, const float*
         GemmProblem p = gemm(c->dh, (size_t)M * I, I, W + o.w1, (size_t)I * D, D, M, D, I, EPI_BF16, c->dln, D);
         TRY(launch_gemm(&p, 1, GEMM_NN, -1, st));
     }
-    TRY(launch_ln_bwd(c->dln, a.h, identity_rows(), a.mean2, a.rstd2, P + o.ln2w, dres, 1, c->dhb, G + o.ln2w, G + o.ln2b, M, D, st));
+    TRY(launch_ln_bwd(c->dln, a.h, identity_rows(), a.mean2, a.rstd2, P + o.ln2w, dres, 1, c->dhb, G + o.ln2w, G + o.ln2b, c->ln_part, M, D, st));
     // attention
     {
         GemmProblem p = gemm(c->dhb, (size_t)M * D, D, W + o.wo, (size_t)D * D, D, M, D, D, EPI_BF16, c->dctx, D);
@@ -313,14 +320,14 @@ int layer_backward(bvc_ctx* c, Stack& s, int li, const LayerOff& o, const float*
         g[1] = gemm(c->dh, (size_t)M * I, I, a.ln2o, (size_t)M * D, D, I, D, M, EPI_F32, G + o.w1, D);
         g[2] = gemm(c->dhb, (size_t)M * D, D, a.ctx, (size_t)M * D, D, D, D, M, EPI_F32, G + o.wo, D);
         g[3] = gemm(c->dqkv, (size_t)M * 3 * D, 3 * D, a.ln1o, (size_t)M * D, D, 3 * D, D, M, EPI_F32, G + o.wqkv, D);
-        set_split(g, 4);
-        TRY(launch_gemm(g, 4, GEMM_TN, -1, st));
+        g[0].rowsum = G + o.b2;     // bias gradients ride along as one extra MFMA column each
+        g[1].rowsum = G + o.b1;
+        g[2].rowsum = G + o.bo;
+        g[3].rowsum = G + o.bqkv;
+        const int tile = plan_dw(g, 4);
+        TRY(launch_gemm(g, 4, GEMM_TN, tile, st));
     }
-    TRY(launch_colsum_bf16(c->dyb, M, D, D, 1.f, G + o.b2, st));
-    TRY(launch_colsum_bf16(c->dh, M, I, I, 1.f, G + o.b1, st));
-    TRY(launch_colsum_bf16(c->dhb, M, D, D, 1.f, G + o.bo, st));
-    TRY(launch_colsum_bf16(c->dqkv, M, 3 * D, 3 * D, 1.f, G + o.bqkv, st));
-    TRY(launch_ln_bwd(c->dln, x_in, identity_rows(), a.mean1, a.rstd1, P + o.ln1w, dres, 1, c->dyb, G + o.ln1w, G + o.ln1b, M, D, st));
+    TRY(launch_ln_bwd(c->dln, x_in, identity_rows(), a.mean1, a.rstd1, P + o.ln1w, dres, 1, c->dyb, G + o.ln1w, G + o.ln1b, c->ln_part, M, D, st));
     return BVC_OK;
 }
 
@@ -413,6 +420,7 @@ int bvc_videomae_create(const bvc_videomae_config* cfg, int max_batch, int num_m
     A(dev_alloc(c, &c->dh, MI));
     A(dev_alloc(c, &c->de2d, Mv * Dd));
     A(dev_alloc(c, &c->delta, std::max(B * H * c->nvis, B * Hd * c->L)));
+    A(dev_alloc(c, &c->ln_part, std::max(ln_bwd_workspace_floats_upto((int)Mv, D), ln_bwd_workspace_floats_upto((int)Md, Dd))));
 #undef A
     std::vector<float> tab;
     sinusoid(tab, c->L, D);
@@ -499,10 +507,10 @@ int bvc_videomae_backward(bvc_ctx* c, const float* grad_loss, float* G, bvc_buck
     {
         GemmProblem p = gemm(c->diff, (size_t)Mm * P, P, c->lnf, (size_t)Mm * Dd, Dd, P, Dd, Mm, EPI_F32, G + L.head_w, Dd);
         p.alpha = cmse; p.alpha_dev = grad_loss;
-        set_split(&p, 1);
-        TRY(launch_gemm(&p, 1, GEMM_TN, -1, st));
+        p.rowsum = G + L.head_b;
+        const int tile = plan_dw(&p, 1);
+        TRY(launch_gemm(&p, 1, GEMM_TN, tile, st));
     }
-    TRY(bvc_op_colsum_bf16(c->diff, Mm, P, P, cmse, grad_loss, G + L.head_b, st));
     {
         GemmProblem p = gemm(c->diff, (size_t)Mm * P, P, W + L.head_w, (size_t)P * Dd, Dd, Mm, Dd, P, EPI_BF16, c->dln, Dd);
         p.alpha = cmse; p.alpha_dev = grad_loss;
@@ -513,7 +521,7 @@ int bvc_videomae_backward(bvc_ctx* c, const float* grad_loss, float* G, bvc_buck
     BVC_CHECK_HIP(hipMemsetAsync(c->dyb, 0, (size_t)Md * Dd * 2, st));
     const RowMap tail{nmask, Lq, nvis};
     TRY(launch_ln_bwd(c->dln, c->dec.x_out, tail, c->meanf, c->rstdf, params + L.norm_w, c->dres_dec, 0, c->dyb,
-                      G + L.norm_w, G + L.norm_b, Mm, Dd, st));
+                      G + L.norm_w, G + L.norm_b, c->ln_part, Mm, Dd, st));
     bucket(L.norm_w, L.total);
     for (int i = c->dec.nlayers - 1; i >= 0; --i) {
         TRY(layer_backward(c, c->dec, i, L.dec[i], c->dec.act[i].x_in, c->dres_dec, G, B, Lq, st));
@@ -525,8 +533,8 @@ int bvc_videomae_backward(bvc_ctx* c, const float* grad_loss, float* G, bvc_buck
     TRY(launch_gather_rows_bf16(c->dres_dec, headrows, c->de2d, Mv, Dd, st));
     {
         GemmProblem p = gemm(c->de2d, (size_t)Mv * Dd, Dd, c->xe_bf, (size_t)Mv * D, D, Dd, D, Mv, EPI_F32, G + L.e2d_w, D);
-        set_split(&p, 1);
-        TRY(launch_gemm(&p, 1, GEMM_TN, -1, st));
+        const int tile = plan_dw(&p, 1);
+        TRY(launch_gemm(&p, 1, GEMM_TN, tile, st));
     }
     {
         GemmProblem p = gemm(c->de2d, (size_t)Mv * Dd, Dd, W + L.e2d_w, (size_t)Dd * D, D, Mv, D, Dd, EPI_F32_BF16, c->dres_enc, D);
@@ -541,10 +549,10 @@ int bvc_videomae_backward(bvc_ctx* c, const float* grad_loss, float* G, bvc_buck
     // patch embedding: weight and bias only (pixels need no gradient)
     {
         GemmProblem p = gemm(c->dyb, (size_t)Mv * D, D, c->Ape, (size_t)Mv * c->Kp, c->Kp, D, c->Kp, Mv, EPI_F32, G + L.pe_w, c->Kp);
-        set_split(&p, 1);
-        TRY(launch_gemm(&p, 1, GEMM_TN, -1, st));
+        p.rowsum = G + L.pe_b;
+        const int tile = plan_dw(&p, 1);
+        TRY(launch_gemm(&p, 1, GEMM_TN, tile, st));
     }
-    TRY(launch_colsum_bf16(c->dyb, Mv, D, D, 1.f, G + L.pe_b, st));
     bucket(0, L.enc.front().ln1w);
     return BVC_OK;
 }
@@ -574,10 +582,10 @@ int bvc_videomae_tap(bvc_ctx* c, const char* name, float* dst, int64_t capacity,
 }
 
 // ------------------------------------------------------------------ operator-level entry points
-int bvc_op_gemm(const bvc_gemm_desc* problems, int count, int layout, int tile_cfg, void* stream) {
+int bvc_op_gemm(const bvc_gemm_desc* problems, int count, int layout, int tile_cfg, int stages, void* stream) {
     BVC_REQUIRE(problems, "op_gemm: null problems");
     BVC_REQUIRE(layout >= 0 && layout <= 2, "op_gemm: bad layout %d", layout);
-    return launch_gemm(problems, count, (GemmLayout)layout, tile_cfg, (hipStream_t)stream);
+    return launch_gemm(problems, count, (GemmLayout)layout, tile_cfg, (hipStream_t)stream, stages);
 }
 int bvc_op_gemm_num_tiles(const bvc_gemm_desc* problem, int tile_cfg) {
     if (!problem) return BVC_ERR_INVALID;
@@ -598,15 +606,23 @@ int bvc_op_layernorm_fwd(const float* x, int rin, int rout, int roff, const floa
     return launch_ln_fwd(x, RowMap{rin, rout, roff}, gamma, beta, (bf16_t*)y, mean, rstd, M, D, eps, (hipStream_t)stream);
 }
 int bvc_op_layernorm_bwd(const void* dy, const float* x, int rin, int rout, int roff, const float* mean, const float* rstd,
-                         const float* gamma, float* dres, int accumulate, void* dres_bf16, float* dgamma, float* dbeta, int M,
-                         int D, void* stream) {
-    BVC_REQUIRE(dy && x && mean && rstd && gamma && dres && dgamma && dbeta, "op_layernorm_bwd: null argument");
+                         const float* gamma, float* dres, int accumulate, void* dres_bf16, float* dgamma, float* dbeta,
+                         float* workspace, int M, int D, void* stream) {
+    BVC_REQUIRE(dy && x && mean && rstd && gamma && dres && dgamma && dbeta && workspace, "op_layernorm_bwd: null argument");
     return launch_ln_bwd((const bf16_t*)dy, x, RowMap{rin, rout, roff}, mean, rstd, gamma, dres, accumulate, (bf16_t*)dres_bf16,
-                         dgamma, dbeta, M, D, (hipStream_t)stream);
+                         dgamma, dbeta, workspace, M, D, (hipStream_t)stream);
 }
+int64_t bvc_op_layernorm_bwd_workspace(int M, int D) { return (int64_t)ln_bwd_workspace_floats(M, D); }
 int bvc_op_colsum_bf16(const void* X, int M, int N, int ld, float alpha, const float* alpha_dev, float* out, void* stream) {
     BVC_REQUIRE(X && out, "op_colsum_bf16: null argument");
     return launch_colsum_bf16_scaled((const bf16_t*)X, M, N, ld, alpha, alpha_dev, out, (hipStream_t)stream);
+}
+int bvc_op_sgd_step(float* params, float* grads, float* momentum_buf, int64_t n, float lr, float momentum, float dampening,
+                    float weight_decay, int nesterov, int first_step, int maximize, const float* grad_scale,
+                    const float* found_inf, int write_unscaled_grads, void* stream) {
+    BVC_REQUIRE(params && grads && n >= 0, "op_sgd_step: bad argument");
+    return launch_sgd_step(params, grads, momentum_buf, (size_t)n, lr, momentum, dampening, weight_decay, nesterov, first_step,
+                           maximize, grad_scale, found_inf, write_unscaled_grads, (hipStream_t)stream);
 }
 int bvc_op_cast_bf16(const float* in, void* out, int64_t n, void* stream) {
     BVC_REQUIRE(in && out && n >= 0, "op_cast_bf16: bad argument");

@@ -80,6 +80,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=16, help="clips per GPU (16 in the reference's slurm scripts)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--torch-sgd", action="store_true", help="use torch.optim.SGD instead of the fused HIP update")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -100,7 +101,10 @@ def main():
     model = bvc.VideoMAEForPreTraining(bvc.VideoMAEConfig()).to(dev).train()
     model._ensure_flat(dev)
     xmodel = bvc.DistributedDataParallel(model, device_ids=[local_rank]) if world > 1 else model
-    opt = torch.optim.SGD(xmodel.parameters(), lr=0.1, momentum=0.9, nesterov=True, weight_decay=0.0)
+    # same constructor arguments as the reference's torch.optim.SGD (pretrain_videomae.py:187-189); the update is one
+    # HIP launch over the flat parameter buffer (--torch-sgd switches back to torch.optim.SGD)
+    SGD = torch.optim.SGD if args.torch_sgd else bvc.optim.SGD
+    opt = SGD(xmodel.parameters(), lr=0.1, momentum=0.9, nesterov=True, weight_decay=0.0)
     scaler = torch.amp.GradScaler("cuda")
     B = args.batch
     clips = synthetic_clips(B, 1234 + rank, dev)

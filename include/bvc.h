@@ -112,8 +112,10 @@ typedef struct bvc_gemm_desc {
     const float* bias; const float* resid; const void* aux; int ldaux;
     const int* rowtok; const float* pos; const float* labels; float* partial;
     int rin, rout;
+    float* rowsum;                  /* TN only: rowsum[m] += alpha * sum_k A(m,k)  (bias gradient of the same dY) */
 } bvc_gemm_desc;
-int bvc_op_gemm(const bvc_gemm_desc* problems, int count, int layout, int tile_cfg, void* stream);
+/* tile_cfg: -1 auto, 0 = 128x128, 1 = 128x64, 2 = 64x64;  stages: -1 auto, 2..4 = LDS ring depth */
+int bvc_op_gemm(const bvc_gemm_desc* problems, int count, int layout, int tile_cfg, int stages, void* stream);
 int bvc_op_gemm_num_tiles(const bvc_gemm_desc* problem, int tile_cfg);
 
 /* softmax(QK^T/8)V for head_dim 64; qkv bf16 [B*N][3*64*H]; replaces HF:181-206 / SDPA (HF:239-252) */
@@ -123,11 +125,19 @@ int bvc_op_attention_bwd(const void* qkv, const void* ctx_in, const void* dctx, 
 /* nn.LayerNorm forward/backward (HF:336-337,484); rows may be strided by (rin, rout, roff), rin<=0 = dense */
 int bvc_op_layernorm_fwd(const float* x, int rin, int rout, int roff, const float* gamma, const float* beta, void* y_bf16,
                          float* mean, float* rstd, int M, int D, float eps, void* stream);
+/* workspace: bvc_op_layernorm_bwd_workspace(M, D) floats of scratch */
 int bvc_op_layernorm_bwd(const void* dy_bf16, const float* x, int rin, int rout, int roff, const float* mean,
                          const float* rstd, const float* gamma, float* dres, int accumulate, void* dres_bf16,
-                         float* dgamma, float* dbeta, int M, int D, void* stream);
+                         float* dgamma, float* dbeta, float* workspace, int M, int D, void* stream);
+int64_t bvc_op_layernorm_bwd_workspace(int M, int D);
 int bvc_op_colsum_bf16(const void* X, int M, int N, int ld, float alpha, const float* alpha_dev, float* out, void* stream);
 int bvc_op_cast_bf16(const float* in, void* out, int64_t n, void* stream);
+/* One-pass torch.optim.SGD(momentum, nesterov) update over a flat f32 range, replacing the optimiser step at
+ * pretrain_videomae.py:187-189,313.  grad_scale / found_inf are GradScaler's device scalars (may be NULL):
+ * gradients are divided by *grad_scale, and nothing is touched when *found_inf != 0. */
+int bvc_op_sgd_step(float* params, float* grads, float* momentum_buf, int64_t n, float lr, float momentum, float dampening,
+                    float weight_decay, int nesterov, int first_step, int maximize, const float* grad_scale,
+                    const float* found_inf, int write_unscaled_grads, void* stream);
 /* boolean mask -> ascending visible / masked token lists (the order x[~mask] / x[mask] produce, HF:121,578-579) */
 int bvc_op_mask_index(const uint8_t* mask, int B, int L, int nvis, int nmask, int* vis_idx, int* msk_idx, int* status, void* stream);
 /* tube patches of the visible tokens in Conv3d weight order (HF:157-177) */

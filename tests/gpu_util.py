@@ -20,7 +20,7 @@ def ptr(t):
 
 
 def gemm_desc(A, B, M, N, K, epi, C, ldc=None, lda=None, ldb=None, alpha=1.0, alpha_dev=None, split_k=1, C2=None,
-              bias=None, resid=None, aux=None, rowtok=None, pos=None, labels=None, partial=None, rin=0, rout=0):
+              bias=None, resid=None, aux=None, rowtok=None, pos=None, labels=None, partial=None, rin=0, rout=0, rowsum=None):
     d = L.GemmDesc()
     d.A, d.B = A.data_ptr(), B.data_ptr()
     d.M, d.N, d.K = M, N, K
@@ -42,12 +42,13 @@ def gemm_desc(A, B, M, N, K, epi, C, ldc=None, lda=None, ldb=None, alpha=1.0, al
     d.labels = labels.data_ptr() if labels is not None else None
     d.partial = partial.data_ptr() if partial is not None else None
     d.rin, d.rout = rin, rout
+    d.rowsum = rowsum.data_ptr() if rowsum is not None else None
     return d
 
 
-def run_gemm(descs, layout, tile_cfg=-1):
+def run_gemm(descs, layout, tile_cfg=-1, stages=-1):
     arr = (L.GemmDesc * len(descs))(*descs)
-    L.check(L.lib().bvc_op_gemm(arr, len(descs), layout, tile_cfg, stream()), "bvc_op_gemm")
+    L.check(L.lib().bvc_op_gemm(arr, len(descs), layout, tile_cfg, stages, stream()), "bvc_op_gemm")
 
 
 def rel_err(a, b):

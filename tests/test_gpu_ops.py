@@ -59,6 +59,36 @@ def test_gemm_f32(layout, tile, M, N, K):
     assert torch.isfinite(C).all()
 
 
+@pytest.mark.parametrize("layout", [G.NT, G.NN, G.TN])
+@pytest.mark.parametrize("tile", [0, 1, 2])
+@pytest.mark.parametrize("stages", [2, 3, 4])
+@pytest.mark.parametrize("K", [64, 128, 192, 640])
+def test_gemm_pipeline_depths(layout, tile, stages, K):
+    # LDS ring depth 2..4 with 1, 2, 3 and 10 K-steps: covers prologues shorter than the ring and the counted-wait tail
+    M, N = 264, 200
+    sa, sb = _shapes(layout, M, N, K)
+    A, B = G.bf16_randn(*sa, seed=13), G.bf16_randn(*sb, seed=14)
+    C = torch.full((M, N), float("nan"), device=dev)
+    G.run_gemm([G.gemm_desc(A, B, M, N, K, G.EPI["F32"], C)], layout, tile, stages)
+    torch.cuda.synchronize()
+    assert G.rel_err(C, _ref_gemm(A, B, layout)) < 1e-5, (layout, tile, stages, K)
+
+
+@pytest.mark.parametrize("tile,stages,split", [(0, 2, 1), (1, 3, 3), (2, 4, 2), (-1, -1, 1)])
+def test_gemm_tn_fused_bias_gradient(tile, stages, split):
+    # dW = dY^T X with db = column sums of dY riding along as an all-ones MFMA column
+    Mtok, Nw, Kw = 1000, 328, 192
+    dY, X = G.bf16_randn(Mtok, Nw, seed=15), G.bf16_randn(Mtok, Kw, seed=16)
+    dW = torch.zeros(Nw, Kw, device=dev)
+    db0 = torch.randn(Nw, device=dev)
+    db = db0.clone()
+    s = torch.tensor([2.0], device=dev)
+    G.run_gemm([G.gemm_desc(dY, X, Nw, Kw, Mtok, G.EPI["F32"], dW, rowsum=db, alpha=0.5, alpha_dev=s, split_k=split)], G.TN, tile, stages)
+    torch.cuda.synchronize()
+    assert G.rel_err(dW, dY.float().t() @ X.float()) < 1e-5
+    assert float((db - (db0 + dY.float().sum(0))).abs().max()) < 2e-3
+
+
 @pytest.mark.parametrize("K", [72, 200, 1000])
 def test_gemm_tn_ragged_contraction(K):
     # weight-gradient product with a contraction length (tokens) that is not a multiple of 64:
@@ -236,7 +266,7 @@ def test_attention_sharp_softmax():
 
 
 # --------------------------------------------------------------------------- LayerNorm, column sums
-@pytest.mark.parametrize("M,D", [(160, 768), (1000, 384), (37, 128), (8, 64), (50, 1024)])
+@pytest.mark.parametrize("M,D", [(160, 768), (1000, 384), (37, 128), (8, 64), (50, 1024), (20000, 384)])
 def test_layernorm_forward_backward(M, D):
     g = torch.Generator().manual_seed(40)
     x = (torch.randn(M, D, generator=g) * 2 + 0.5).to(dev)
@@ -256,8 +286,9 @@ def test_layernorm_forward_backward(M, D):
     dres = dres0.clone()
     dres_bf = torch.zeros(M, D, device=dev, dtype=torch.bfloat16)
     dg, db = torch.zeros(D, device=dev), torch.zeros(D, device=dev)
+    ws = torch.zeros(int(L.lib().bvc_op_layernorm_bwd_workspace(M, D)), device=dev)
     L.check(L.lib().bvc_op_layernorm_bwd(G.ptr(dy), G.ptr(x), 0, 0, 0, G.ptr(mean), G.ptr(rstd), G.ptr(gamma), G.ptr(dres), 1,
-                                         G.ptr(dres_bf), G.ptr(dg), G.ptr(db), M, D, G.stream()), "ln_bwd")
+                                         G.ptr(dres_bf), G.ptr(dg), G.ptr(db), G.ptr(ws), M, D, G.stream()), "ln_bwd")
     torch.cuda.synchronize()
     ref.backward(dy.float())
     assert G.rel_err(dres - dres0, xr.grad) < 1e-4
@@ -343,3 +374,69 @@ def test_cast_bf16():
     L.check(L.lib().bvc_op_cast_bf16(G.ptr(x), G.ptr(y), x.numel(), G.stream()), "cast")
     torch.cuda.synchronize()
     assert torch.equal(y, x.to(torch.bfloat16))   # round-to-nearest-even, bit-exact
+
+
+# --------------------------------------------------------------------------- fused SGD
+@pytest.mark.parametrize("momentum,nesterov,wd,damp", [(0.9, True, 0.0, 0.0), (0.9, False, 1e-2, 0.0), (0.0, False, 0.0, 0.0), (0.8, False, 0.0, 0.3)])
+def test_fused_sgd_matches_torch(momentum, nesterov, wd, damp):
+    """bvc.optim.SGD over a flat buffer vs torch.optim.SGD (the reference's optimiser, pretrain_videomae.py:187-189)."""
+    torch.manual_seed(0)
+    shapes = [(64, 32), (32,), (7, 5, 3), (1001,)]
+    n = sum(int(np.prod(s)) for s in shapes)
+    flat, gflat = torch.randn(n, device=dev), torch.zeros(n, device=dev)
+    mine, ref, o = [], [], 0
+    for shp in shapes:
+        k = int(np.prod(shp))
+        p = torch.nn.Parameter(flat[o:o + k].view(shp))
+        p.grad = gflat[o:o + k].view(shp)
+        mine.append(p)
+        ref.append(torch.nn.Parameter(flat[o:o + k].view(shp).clone()))
+        o += k
+    a = G.bvc.optim.SGD(mine, lr=0.1, momentum=momentum, nesterov=nesterov, weight_decay=wd, dampening=damp)
+    b = torch.optim.SGD(ref, lr=0.1, momentum=momentum, nesterov=nesterov, weight_decay=wd, dampening=damp, foreach=False)
+    for it in range(4):
+        g = torch.randn(n, device=dev)
+        gflat.copy_(g)
+        o = 0
+        for r in ref:
+            r.grad = g[o:o + r.numel()].view(r.shape).clone()
+            o += r.numel()
+        a.step()
+        b.step()
+        torch.cuda.synchronize()
+        for p, r in zip(mine, ref):
+            torch.testing.assert_close(p.data, r.data, rtol=2e-6, atol=2e-7)
+    if momentum:
+        sa, sb = a.state_dict(), b.state_dict()
+        assert set(sa["state"][0].keys()) == set(sb["state"][0].keys()) == {"momentum_buffer"}
+        torch.testing.assert_close(sa["state"][3]["momentum_buffer"], sb["state"][3]["momentum_buffer"], rtol=2e-6, atol=2e-7)
+    assert len(a._runs[0][1]) == 1   # one contiguous run -> one launch
+
+
+def test_fused_sgd_with_gradscaler_skips_on_inf():
+    n = 4096
+    flat, gflat = torch.randn(n, device=dev), torch.zeros(n, device=dev)
+    p = torch.nn.Parameter(flat.view(64, 64))
+    opt = G.bvc.optim.SGD([p], lr=0.5, momentum=0.9, nesterov=True)
+    scaler = torch.amp.GradScaler("cuda", init_scale=1024.0)
+    scaler.scale(torch.zeros((), device=dev))   # GradScaler creates its device-side scale lazily
+    ref = flat.clone()
+    buf = torch.zeros_like(ref)
+    for it, poison in enumerate([False, True, False]):
+        g = torch.randn(n, device=dev)
+        scaled = g * scaler.get_scale()
+        if poison:
+            scaled[5] = float("inf")
+        p.grad = gflat.view(64, 64)
+        gflat.copy_(scaled)
+        scaler.step(opt)        # no host sync inside: grad_scale / found_inf stay on the device
+        before = scaler.get_scale()
+        scaler.update()
+        if poison:
+            assert scaler.get_scale() == before * 0.5
+        else:
+            buf = buf * 0.9 + g
+            ref = ref - 0.5 * (g + 0.9 * buf)
+            torch.testing.assert_close(gflat, g, rtol=1e-6, atol=1e-6)   # unscaled gradient written back
+        torch.cuda.synchronize()
+        torch.testing.assert_close(flat, ref, rtol=1e-5, atol=1e-5)

@@ -169,13 +169,16 @@ def test_bad_mask_makes_loss_nan():
         model(pixels.to(dev), bool_masked_pos=bad.to(dev))
 
 
-def test_training_loop_with_gradscaler_and_sgd():
+@pytest.mark.parametrize("fused", [False, True])
+def test_training_loop_with_gradscaler_and_sgd(fused):
     """The reference's loop body (pretrain_videomae.py:300-317): zero_grad, forward, scaler.scale(loss).backward(),
     scaler.step, scaler.update, grad_logger - three steps against the oracle's SGD-Nesterov restatement."""
     cfg = vo.TINY
     params = vo.make_params(cfg, seed=2)
     model = _model(cfg, params)
-    opt = torch.optim.SGD(model.parameters(), lr=0.1, momentum=0.9, nesterov=True, weight_decay=0.0)
+    model._ensure_flat(dev)
+    SGD = bvc.optim.SGD if fused else torch.optim.SGD     # fused: one HIP launch over the flat buffer
+    opt = SGD(model.parameters(), lr=0.1, momentum=0.9, nesterov=True, weight_decay=0.0)
     scaler = torch.amp.GradScaler("cuda")
     ref = {k: v.clone() for k, v in params.items()}
     bufs = {}

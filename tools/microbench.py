@@ -27,7 +27,7 @@ def timeit(fn, iters=20, warm=3):
     return e0.elapsed_time(e1) / iters
 
 
-def gemm_case(name, layout, M, N, K, tile=-1, split=1, epi="BF16"):
+def gemm_case(name, layout, M, N, K, tile=-1, split=1, epi="BF16", stages=-1):
     if layout == G.NT:
         A, B = G.bf16_randn(M, K), G.bf16_randn(N, K)
     elif layout == G.NN:
@@ -36,9 +36,9 @@ def gemm_case(name, layout, M, N, K, tile=-1, split=1, epi="BF16"):
         A, B = G.bf16_randn(K, M), G.bf16_randn(K, N)
     C = torch.zeros(M, N, device=dev, dtype=torch.float32 if epi == "F32" else torch.bfloat16)
     d = G.gemm_desc(A, B, M, N, K, G.EPI[epi], C, split_k=split)
-    ms = timeit(lambda: G.run_gemm([d], layout, tile))
+    ms = timeit(lambda: G.run_gemm([d], layout, tile, stages))
     tf = 2.0 * M * N * K / (ms * 1e-3) / 1e12
-    return {"name": name, "layout": ["NT", "NN", "TN"][layout], "M": M, "N": N, "K": K, "tile": tile, "split": split,
+    return {"name": name, "layout": ["NT", "NN", "TN"][layout], "M": M, "N": N, "K": K, "tile": tile, "stages": stages, "split": split,
             "ms": round(ms, 4), "tflops": round(tf, 1)}
 
 
@@ -66,25 +66,47 @@ def main():
         ("enc qkv", G.NT, Me, 2304, 768), ("enc proj", G.NT, Me, 768, 768), ("enc fc1", G.NT, Me, 3072, 768), ("enc fc2", G.NT, Me, 768, 3072),
         ("dec qkv", G.NT, Md, 1152, 384), ("dec proj", G.NT, Md, 384, 384), ("dec fc1", G.NT, Md, 1536, 384), ("dec fc2", G.NT, Md, 384, 1536),
         ("head", G.NT, Mm, 1536, 384), ("patch", G.NT, Me, 768, 1536),
-        ("enc dX fc2", G.NN, Me, 3072, 768), ("enc dX fc1", G.NN, Me, 768, 3072), ("enc dX qkv", G.NN, Me, 768, 2304),
-        ("dec dX fc2", G.NN, Md, 1536, 384), ("dec dX fc1", G.NN, Md, 384, 1536), ("dec dX qkv", G.NN, Md, 384, 1152),
-        ("enc dW fc1", G.TN, 3072, 768, Me), ("enc dW qkv", G.TN, 2304, 768, Me), ("dec dW fc1", G.TN, 1536, 384, Md),
-        ("square 4096", G.NT, 4096, 4096, 4096), ("square 8192", G.NT, 8192, 8192, 8192),
+        ("enc dX fc2", G.NN, Me, 3072, 768), ("enc dX fc1", G.NN, Me, 768, 3072), ("enc dX qkv", G.NN, Me, 768, 2304), ("enc dX proj", G.NN, Me, 768, 768),
+        ("dec dX fc2", G.NN, Md, 1536, 384), ("dec dX fc1", G.NN, Md, 384, 1536), ("dec dX qkv", G.NN, Md, 384, 1152), ("dec dX proj", G.NN, Md, 384, 384),
+        ("enc dW fc1", G.TN, 3072, 768, Me), ("enc dW fc2", G.TN, 768, 3072, Me), ("enc dW qkv", G.TN, 2304, 768, Me), ("dec dW fc1", G.TN, 1536, 384, Md),
+        ("square 4096", G.NT, 4096, 4096, 4096),
     ]
+    sweep = os.environ.get("BVC_SWEEP", "1") == "1"
     for name, lay, M, N, K in cases:
-        for tile in ((-1,) if "square" not in name else (0,)):
-            split = 1
-            epi = "F32" if lay == G.TN else "BF16"
-            if lay == G.TN and "dec" in name:
-                split = 5
-            r = gemm_case(name, lay, M, N, K, tile, split, epi)
+        epi = "F32" if lay == G.TN else "BF16"
+        split = 5 if (lay == G.TN and "dec" in name) else 1
+        combos = [(-1, -1)]
+        if sweep:
+            combos += [(t, s) for t in (0, 1, 2) for s in (2, 3, 4)]
+        best = None
+        for tile, st in combos:
+            r = gemm_case(name, lay, M, N, K, tile, split, epi, st)
             out.append(r)
-            print(r, flush=True)
-    for tile in (0, 1, 2):
-        r = gemm_case(f"enc proj tile{tile}", G.NT, Me, 768, 768, tile)
-        out.append(r); print(r, flush=True)
-        r = gemm_case(f"dec fc1 tile{tile}", G.NT, Md, 1536, 384, tile)
-        out.append(r); print(r, flush=True)
+            if tile >= 0 and (best is None or r["ms"] < best["ms"]):
+                best = r
+            if tile < 0:
+                auto = r
+        if best:
+            print(f"{name:12s} auto {auto['ms']*1e3:7.1f}us {auto['tflops']:6.1f}TF | best tile{best['tile']} st{best['stages']} {best['ms']*1e3:7.1f}us {best['tflops']:6.1f}TF", flush=True)
+        else:
+            print(auto, flush=True)
+    # the grouped weight-gradient launch of one layer (4 problems, fused bias gradients)
+    for tag, M, D, I in (("enc", Me, 768, 3072), ("dec", Md, 384, 1536)):
+        dy, act = G.bf16_randn(M, D, seed=7), G.bf16_randn(M, I, seed=8)
+        dh, ln2 = G.bf16_randn(M, I, seed=9), G.bf16_randn(M, D, seed=10)
+        dqkv = G.bf16_randn(M, 3 * D, seed=11)
+        outs = [torch.zeros(D, I, device=dev), torch.zeros(I, D, device=dev), torch.zeros(D, D, device=dev), torch.zeros(3 * D, D, device=dev)]
+        bs = [torch.zeros(D, device=dev), torch.zeros(I, device=dev), torch.zeros(D, device=dev), torch.zeros(3 * D, device=dev)]
+        flops = 2.0 * M * (D * I * 2 + D * D * 4)
+        for split in ((1, 2) if tag == "enc" else (2, 4, 6)):
+            for tile in (0, 1, 2):
+                descs = [G.gemm_desc(dy, act, D, I, M, G.EPI["F32"], outs[0], rowsum=bs[0], split_k=split),
+                         G.gemm_desc(dh, ln2, I, D, M, G.EPI["F32"], outs[1], rowsum=bs[1], split_k=split),
+                         G.gemm_desc(dy, ln2, D, D, M, G.EPI["F32"], outs[2], rowsum=bs[2], split_k=split),
+                         G.gemm_desc(dqkv, ln2, 3 * D, D, M, G.EPI["F32"], outs[3], rowsum=bs[3], split_k=split)]
+                ms = timeit(lambda: G.run_gemm(descs, G.TN, tile, 2))
+                r = {"name": f"{tag} dW group", "tile": tile, "split": split, "ms": round(ms, 4), "tflops": round(flops / ms / 1e9, 1)}
+                out.append(r); print(r, flush=True)
     for (B, N, H) in [(Bc, 160, 12), (Bc, 1568, 6)]:
         r = attn_case(B, N, H)
         out.append(r); print(r, flush=True)

@@ -17,15 +17,29 @@
 // round-trips through LDS.  dS/dP are recomputed in the dQ kernel (7 instead of 5 products) in
 // exchange for a deterministic, atomic-free dQ.
 //
+// At head_dim 64 these kernels are VALU-issue bound (rocprofv3: 45 VALU per MFMA in the first version), so the
+// loops are written to keep the VALU count down:
+//   * __launch_bounds__(256, 2): <= 256 registers makes hipcc pick the VGPR form of the MFMA, so
+//     accumulators are scaled / exponentiated in place (no v_accvgpr_read/write round trips);
+//   * raw v_exp_f32 (arguments are <= 0 or bounded, no denormal fix-up), one v_cvt_pk_bf16_f32 per pair;
+//   * every LDS fragment address is a per-lane constant computed once; stage / sub-tile / k-step are
+//     immediate offsets (the tile loop is unrolled over the two LDS stages);
+//   * the ragged last key tile is masked in its own branch, not with per-element selects;
+//   * the O rescale is skipped while the running maximum grows by < 2^6 (P stays <= 64, exact in f32 sums).
+//
 // K/V (or Q/dO) tiles of 64 rows x 64 bf16 go HBM -> LDS by LDS-DMA into a 2-stage ring, XOR-swizzled
 // so that both the ds_read_b128 row reads and the transposed reads of the same image are
-// bank-conflict free.
+// bank-conflict free (SQ_LDS_BANK_CONFLICT = 0 measured).
 #include "attention.h"
 
 namespace bvc {
 
+#define AS3 __attribute__((address_space(3)))
+#define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+
 // swizzle of the 16-B chunk index of row r in a [rows][64] bf16 tile (128-B rows); serves both
-// ds_read_b128 row fragments (16 rows, one chunk) and tr reads (4 rows x 4 chunks)
+// ds_read_b128 row fragments (16 rows, one chunk) and tr reads (4 rows x 4 chunks).  Uses bits 1..3 of r
+// only, so adding a multiple of 16 rows to r is a plain byte offset.
 __device__ __forceinline__ int swz_dual(int r) { return (((r >> 1) & 1) << 2) | ((r >> 2) & 3); }
 
 // stage rows [row0, row0+64) x 64 bf16 starting at element column `col0` of a [rows][ld] bf16 array
@@ -42,31 +56,45 @@ __device__ __forceinline__ void stage64(__amdgpu_buffer_rsrc_t rs, int row0, int
     }
 }
 
-// row fragment for the 32x32x16 A operand: lane (r = l&31, h = l>>5) gets tile[rbase + r][16 step + 8 h + 0..7]
-__device__ __forceinline__ bf16x8 frag_rows(const char* lds, int rbase, int step, int lane) {
-    const int r = rbase + (lane & 31);
-    const int c = 2 * step + (lane >> 5);
-    return *reinterpret_cast<const __attribute__((address_space(3))) bf16x8*>(
-        (const __attribute__((address_space(3))) char*)(lds) + r * 128 + ((c ^ swz_dual(r)) << 4));
+// Per-lane fragment addresses (byte offsets inside one 8 KiB tile image), computed once per kernel.
+//   rows[st]    : row fragment of the 32x32x16 A operand, lane (r = l&31, h = l>>5) ->
+//                 tile[r][16 st + 8 h + 0..7];   sub-tile s adds 4096 B
+//   tr[t][half] : transposed fragment, lane (i = l&31, h) -> tile[4 h + q + 8 half (+16 ks)][32 t + i];
+//                 k-step ks adds 2048 B, sub-tile s adds 4096 B
+struct FragAddr {
+    uint32_t rows[4];
+    uint32_t tr[2][2];
+};
+
+__device__ __forceinline__ FragAddr make_frag_addr(int lane) {
+    FragAddr a;
+    const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int st = 0; st < 4; ++st) a.rows[st] = r * 128 + (((2 * st + h) ^ swz_dual(r)) << 4);
+    const int q = (lane >> 2) & 3, p = lane & 3;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int col = 32 * t + 16 * ((lane >> 4) & 1) + 4 * p;
+        const int chunk = col >> 3, within = (col & 7) * 2;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int r0 = 4 * h + q + 8 * half;
+            a.tr[t][half] = r0 * 128 + ((chunk ^ swz_dual(r0)) << 4) + within;
+        }
+    }
+    return a;
 }
 
-// transposed fragment for the A operand of a product that sums over the tile's ROW index with the
-// permuted k order of an in-register accumulator operand: lane (i = l&31, h) gets
-// tile[rbase + 16 s + 8 (j>>2) + 4 h + (j&3)][cbase + i] for j = 0..7
-__device__ __forceinline__ bf16x8 frag_tr(const char* lds, int rbase, int s, int cbase, int lane) {
-    const int h = lane >> 5, q = (lane >> 2) & 3, p = lane & 3;
-    const int col = cbase + 16 * ((lane >> 4) & 1) + 4 * p;
-    const int chunk = col >> 3, within = (col & 7) * 2;
-    const int r0 = rbase + 16 * s + 4 * h + q, r1 = r0 + 8;
-    const __attribute__((address_space(3))) char* base = (const __attribute__((address_space(3))) char*)(lds);
-    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-        (__attribute__((address_space(3))) bf16x4*)(base + r0 * 128 + ((chunk ^ swz_dual(r0)) << 4) + within));
-    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-        (__attribute__((address_space(3))) bf16x4*)(base + r1 * 128 + ((chunk ^ swz_dual(r1)) << 4) + within));
-    bf16x8 r;
-    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
-    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
-    return r;
+template <int IMM>
+__device__ __forceinline__ bf16x8 lds_rows(const AS3 char* base, uint32_t off) {
+    return *reinterpret_cast<const AS3 bf16x8*>(base + off + IMM);
+}
+
+template <int IMM>
+__device__ __forceinline__ bf16x8 lds_tr(const AS3 char* base, uint32_t off_lo, uint32_t off_hi) {
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((AS3 bf16x4*)(base + off_lo + IMM));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((AS3 bf16x4*)(base + off_hi + IMM));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
 // accumulator registers 8s..8s+7 -> bf16 fragment (B operand of the next product)
@@ -83,8 +111,6 @@ __device__ __forceinline__ int acc_row(int reg, int h) { return (reg & 3) + 8 * 
 // 8 consecutive bf16 of one row straight from HBM (row clamped by the caller)
 __device__ __forceinline__ bf16x8 load8(const bf16_t* p) { return *reinterpret_cast<const bf16x8*>(p); }
 
-#define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
-
 __device__ __forceinline__ f32x16 zero16() {
     f32x16 z;
 #pragma unroll
@@ -92,12 +118,74 @@ __device__ __forceinline__ f32x16 zero16() {
     return z;
 }
 
+// max / sum across the two lane halves (lanes l and l+32 hold the two halves of one softmax row)
+__device__ __forceinline__ float xhalf_max(float v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float xhalf_sum(float v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+constexpr float kDeferLog2 = 6.0f;   // rescale O only when the running max grows by more than 2^6
+
 // ============================================================================ forward
+struct FwdState {
+    f32x16 o0, o1;       // O^T rows d = 0..31 / 32..63, column = query
+    float m_run, l_run;  // running max (log2 units), this lane half's share of the row sum
+};
+
+// one 32-key sub-tile; KOFF / VOFF = byte offsets of the K and V images of the stage (+ sub-tile)
+template <int KOFF, int VOFF>
+__device__ __forceinline__ void fwd_subtile(const AS3 char* lds, const FragAddr& fa, const bf16x8 (&qf)[4], FwdState& st,
+                                            int key0, int N, int h, float scale_log2) {
+    f32x16 s = zero16();
+    s = MFMA32(lds_rows<KOFF>(lds, fa.rows[0]), qf[0], s);
+    s = MFMA32(lds_rows<KOFF>(lds, fa.rows[1]), qf[1], s);
+    s = MFMA32(lds_rows<KOFF>(lds, fa.rows[2]), qf[2], s);
+    s = MFMA32(lds_rows<KOFF>(lds, fa.rows[3]), qf[3], s);
+    if (key0 + 32 > N) {   // ragged last tile only (workgroup-uniform branch)
+        asm volatile("" ::: "memory");   // keep it a branch: if-converted, it costs 3 VALU per element on EVERY tile
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            if (key0 + acc_row(r, h) >= N) s[r] = -INFINITY;
+    }
+    float mx = s[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
+    mx = xhalf_max(mx) * scale_log2;
+    if (!__all(mx - st.m_run <= kDeferLog2)) {   // wave-uniform: raise the running max, rescale what is accumulated
+        const float m_new = fmaxf(st.m_run, mx);
+        const float alpha = fast_exp2(st.m_run - m_new);
+        st.m_run = m_new;
+        st.l_run *= alpha;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { st.o0[r] *= alpha; st.o1[r] *= alpha; }
+    }
+    const float nm = -st.m_run;
+    float rs = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        s[r] = fast_exp2(fmaf(s[r], scale_log2, nm));
+        rs += s[r];
+    }
+    st.l_run += rs;
+    const bf16x8 p0 = acc_to_frag(s, 0), p1 = acc_to_frag(s, 1);
+    st.o0 = MFMA32(lds_tr<VOFF>(lds, fa.tr[0][0], fa.tr[0][1]), p0, st.o0);
+    st.o1 = MFMA32(lds_tr<VOFF>(lds, fa.tr[1][0], fa.tr[1][1]), p0, st.o1);
+    st.o0 = MFMA32(lds_tr<VOFF + 2048>(lds, fa.tr[0][0], fa.tr[0][1]), p1, st.o0);
+    st.o1 = MFMA32(lds_tr<VOFF + 2048>(lds, fa.tr[1][0], fa.tr[1][1]), p1, st.o1);
+}
+
 // grid (ceil(N/128), B*H); 256 threads; wave w owns queries q0 + 32 w .. + 31
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx,
-                                                       float* __restrict__ lse, int N, int H, int D,
-                                                       uint32_t qkv_bytes, float scale_log2) {
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx,
+                                                          float* __restrict__ lse, int N, int H, int D,
+                                                          uint32_t qkv_bytes, float scale_log2) {
     extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 stages x (K 8 KiB + V 8 KiB)
+    const AS3 char* lds = (const AS3 char*)smem;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int bh = blockIdx.y, b = bh / H, head = bh % H;
@@ -105,80 +193,51 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
     const int qi = blockIdx.x * 128 + wave * 32 + (lane & 31);   // this lane's query
     const int h = lane >> 5;
     const __amdgpu_buffer_rsrc_t rs = make_rsrc(qkv, qkv_bytes);
+    const FragAddr fa = make_frag_addr(lane);
 
-    // Q^T fragments (B operand of S^T = K Q^T): Q[qi][16 step + 8 h + 0..7]
-    bf16x8 qf[4];
+    bf16x8 qf[4];   // Q^T fragments (B operand of S^T = K Q^T): Q[qi][16 step + 8 h + 0..7]
     {
         const bf16_t* qrow = qkv + (size_t)(b * N + min(qi, N - 1)) * ld + head * 64 + 8 * h;
 #pragma unroll
         for (int st = 0; st < 4; ++st) qf[st] = load8(qrow + 16 * st);
     }
-    f32x16 o0 = zero16(), o1 = zero16();   // O^T rows d = 0..31 / 32..63, column = query
-    float m_run = -INFINITY, l_run = 0.f;  // running max (log2 units) and this half's share of the sum
+    FwdState st;
+    st.o0 = zero16(); st.o1 = zero16();
+    st.m_run = -INFINITY; st.l_run = 0.f;
 
     const int nkt = (N + 63) >> 6;
     const int krow0 = b * N;
-    stage64(rs, krow0, ld, D + head * 64, smem, wave, lane);
-    stage64(rs, krow0, ld, 2 * D + head * 64, smem + 8192, wave, lane);
-    for (int kt = 0; kt < nkt; ++kt) {
+    auto issue = [&](int kt, int stage) {
+        stage64(rs, krow0 + kt * 64, ld, D + head * 64, smem + stage * 16384, wave, lane);
+        stage64(rs, krow0 + kt * 64, ld, 2 * D + head * 64, smem + stage * 16384 + 8192, wave, lane);
+    };
+    issue(0, 0);
+    for (int kt = 0; kt < nkt; kt += 2) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (kt + 1 < nkt) {
-            char* nx = smem + ((kt + 1) & 1) * 16384;
-            stage64(rs, krow0 + (kt + 1) * 64, ld, D + head * 64, nx, wave, lane);
-            stage64(rs, krow0 + (kt + 1) * 64, ld, 2 * D + head * 64, nx + 8192, wave, lane);
-        }
-        const char* kl = smem + (kt & 1) * 16384;
-        const char* vl = kl + 8192;
-#pragma unroll
-        for (int sub = 0; sub < 2; ++sub) {
-            const int key0 = kt * 64 + sub * 32;
-            if (key0 >= N) break;   // workgroup-uniform
-            f32x16 s = zero16();
-#pragma unroll
-            for (int st = 0; st < 4; ++st) s = MFMA32(frag_rows(kl, sub * 32, st, lane), qf[st], s);
-            // ---- online softmax, one query per lane, 16 of the 32 keys in this lane half
-            float mx = -INFINITY;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                if (key0 + 32 > N && key0 + acc_row(r, h) >= N) s[r] = -INFINITY;
-                mx = fmaxf(mx, s[r]);
-            }
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float m_new = fmaxf(m_run, mx * scale_log2);
-            const float alpha = exp2f(m_run - m_new);
-            m_run = m_new;
-            float rs_ = 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                s[r] = exp2f(s[r] * scale_log2 - m_new);
-                rs_ += s[r];
-            }
-            l_run = l_run * alpha + rs_;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
-            // ---- O^T += V^T P^T
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const bf16x8 pf = acc_to_frag(s, ks);
-                o0 = MFMA32(frag_tr(vl, sub * 32, ks, 0, lane), pf, o0);
-                o1 = MFMA32(frag_tr(vl, sub * 32, ks, 32, lane), pf, o1);
-            }
-        }
+        if (kt + 1 < nkt) issue(kt + 1, 1);
+        fwd_subtile<0, 8192>(lds, fa, qf, st, kt * 64, N, h, scale_log2);
+        if (kt * 64 + 32 < N) fwd_subtile<4096, 8192 + 4096>(lds, fa, qf, st, kt * 64 + 32, N, h, scale_log2);
+        if (kt + 1 >= nkt) break;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (kt + 2 < nkt) issue(kt + 2, 0);
+        fwd_subtile<16384, 16384 + 8192>(lds, fa, qf, st, kt * 64 + 64, N, h, scale_log2);
+        if (kt * 64 + 96 < N) fwd_subtile<16384 + 4096, 16384 + 8192 + 4096>(lds, fa, qf, st, kt * 64 + 96, N, h, scale_log2);
     }
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float l_tot = xhalf_sum(st.l_run);
     const float inv = 1.f / l_tot;
     if (qi < N) {
         bf16_t* orow = ctx + (size_t)(b * N + qi) * D + head * 64;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int d = 8 * g + 4 * h;
-            uint2 a = {pack2bf(o0[4 * g] * inv, o0[4 * g + 1] * inv), pack2bf(o0[4 * g + 2] * inv, o0[4 * g + 3] * inv)};
-            uint2 c = {pack2bf(o1[4 * g] * inv, o1[4 * g + 1] * inv), pack2bf(o1[4 * g + 2] * inv, o1[4 * g + 3] * inv)};
+            uint2 a = {pack2bf(st.o0[4 * g] * inv, st.o0[4 * g + 1] * inv), pack2bf(st.o0[4 * g + 2] * inv, st.o0[4 * g + 3] * inv)};
+            uint2 c = {pack2bf(st.o1[4 * g] * inv, st.o1[4 * g + 1] * inv), pack2bf(st.o1[4 * g + 2] * inv, st.o1[4 * g + 3] * inv)};
             *reinterpret_cast<uint2*>(orow + d) = a;
             *reinterpret_cast<uint2*>(orow + 32 + d) = c;
         }
-        if (h == 0) lse[(size_t)bh * N + qi] = m_run + log2f(l_tot);
+        if (h == 0) lse[(size_t)bh * N + qi] = st.m_run + log2f(l_tot);
     }
 }
 
@@ -211,12 +270,39 @@ __global__ void attn_delta_kernel(const bf16_t* __restrict__ dctx, const bf16_t*
 }
 
 // ============================================================================ dQ
+template <int KOFF, int VOFF>
+__device__ __forceinline__ void dq_subtile(const AS3 char* lds, const FragAddr& fa, const bf16x8 (&qf)[4], const bf16x8 (&dof)[4],
+                                           f32x16& dq0, f32x16& dq1, int key0, int N, int h, float scale_log2,
+                                           float nlse, float del_q) {
+    f32x16 s = zero16(), dp = zero16();
+#pragma unroll
+    for (int stp = 0; stp < 4; ++stp) {
+        s = MFMA32(lds_rows<KOFF>(lds, fa.rows[stp]), qf[stp], s);
+        dp = MFMA32(lds_rows<VOFF>(lds, fa.rows[stp]), dof[stp], dp);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r)   // dS^T (without the 1/sqrt(d) factor, applied at the end)
+        s[r] = fast_exp2(fmaf(s[r], scale_log2, nlse)) * (dp[r] - del_q);
+    if (key0 + 32 > N) {
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            if (key0 + acc_row(r, h) >= N) s[r] = 0.f;
+    }
+    const bf16x8 d0 = acc_to_frag(s, 0), d1 = acc_to_frag(s, 1);
+    dq0 = MFMA32(lds_tr<KOFF>(lds, fa.tr[0][0], fa.tr[0][1]), d0, dq0);
+    dq1 = MFMA32(lds_tr<KOFF>(lds, fa.tr[1][0], fa.tr[1][1]), d0, dq1);
+    dq0 = MFMA32(lds_tr<KOFF + 2048>(lds, fa.tr[0][0], fa.tr[0][1]), d1, dq0);
+    dq1 = MFMA32(lds_tr<KOFF + 2048>(lds, fa.tr[1][0], fa.tr[1][1]), d1, dq1);
+}
+
 // grid (ceil(N/128), B*H); wave w owns 32 queries; loops over key tiles (K and V staged)
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dctx,
-                                                          const float* __restrict__ lse, const float* __restrict__ delta,
-                                                          bf16_t* __restrict__ dqkv, int N, int H, int D,
-                                                          uint32_t qkv_bytes, float scale, float scale_log2) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dctx,
+                                                             const float* __restrict__ lse, const float* __restrict__ delta,
+                                                             bf16_t* __restrict__ dqkv, int N, int H, int D,
+                                                             uint32_t qkv_bytes, float scale, float scale_log2) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    const AS3 char* lds = (const AS3 char*)smem;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int bh = blockIdx.y, b = bh / H, head = bh % H;
@@ -225,6 +311,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
     const int qc = min(qi, N - 1);
     const int h = lane >> 5;
     const __amdgpu_buffer_rsrc_t rs = make_rsrc(qkv, qkv_bytes);
+    const FragAddr fa = make_frag_addr(lane);
 
     bf16x8 qf[4], dof[4];
     {
@@ -233,47 +320,30 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
 #pragma unroll
         for (int st = 0; st < 4; ++st) { qf[st] = load8(qrow + 16 * st); dof[st] = load8(drow + 16 * st); }
     }
-    const float lse_q = lse[(size_t)bh * N + qc];
+    const float nlse = -lse[(size_t)bh * N + qc];
     const float del_q = delta[(size_t)bh * N + qc];
     f32x16 dq0 = zero16(), dq1 = zero16();
 
     const int nkt = (N + 63) >> 6;
     const int krow0 = b * N;
-    stage64(rs, krow0, ld, D + head * 64, smem, wave, lane);
-    stage64(rs, krow0, ld, 2 * D + head * 64, smem + 8192, wave, lane);
-    for (int kt = 0; kt < nkt; ++kt) {
+    auto issue = [&](int kt, int stage) {
+        stage64(rs, krow0 + kt * 64, ld, D + head * 64, smem + stage * 16384, wave, lane);
+        stage64(rs, krow0 + kt * 64, ld, 2 * D + head * 64, smem + stage * 16384 + 8192, wave, lane);
+    };
+    issue(0, 0);
+    for (int kt = 0; kt < nkt; kt += 2) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (kt + 1 < nkt) {
-            char* nx = smem + ((kt + 1) & 1) * 16384;
-            stage64(rs, krow0 + (kt + 1) * 64, ld, D + head * 64, nx, wave, lane);
-            stage64(rs, krow0 + (kt + 1) * 64, ld, 2 * D + head * 64, nx + 8192, wave, lane);
-        }
-        const char* kl = smem + (kt & 1) * 16384;
-        const char* vl = kl + 8192;
-#pragma unroll
-        for (int sub = 0; sub < 2; ++sub) {
-            const int key0 = kt * 64 + sub * 32;
-            if (key0 >= N) break;
-            f32x16 s = zero16(), dp = zero16();
-#pragma unroll
-            for (int st = 0; st < 4; ++st) {
-                s = MFMA32(frag_rows(kl, sub * 32, st, lane), qf[st], s);
-                dp = MFMA32(frag_rows(vl, sub * 32, st, lane), dof[st], dp);
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float p = exp2f(s[r] * scale_log2 - lse_q);
-                if (key0 + 32 > N && key0 + acc_row(r, h) >= N) p = 0.f;
-                s[r] = p * (dp[r] - del_q);   // dS^T (without the 1/sqrt(d) factor, applied at the end)
-            }
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const bf16x8 df = acc_to_frag(s, ks);
-                dq0 = MFMA32(frag_tr(kl, sub * 32, ks, 0, lane), df, dq0);
-                dq1 = MFMA32(frag_tr(kl, sub * 32, ks, 32, lane), df, dq1);
-            }
-        }
+        if (kt + 1 < nkt) issue(kt + 1, 1);
+        dq_subtile<0, 8192>(lds, fa, qf, dof, dq0, dq1, kt * 64, N, h, scale_log2, nlse, del_q);
+        if (kt * 64 + 32 < N) dq_subtile<4096, 8192 + 4096>(lds, fa, qf, dof, dq0, dq1, kt * 64 + 32, N, h, scale_log2, nlse, del_q);
+        if (kt + 1 >= nkt) break;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (kt + 2 < nkt) issue(kt + 2, 0);
+        dq_subtile<16384, 16384 + 8192>(lds, fa, qf, dof, dq0, dq1, kt * 64 + 64, N, h, scale_log2, nlse, del_q);
+        if (kt * 64 + 96 < N)
+            dq_subtile<16384 + 4096, 16384 + 8192 + 4096>(lds, fa, qf, dof, dq0, dq1, kt * 64 + 96, N, h, scale_log2, nlse, del_q);
     }
     if (qi < N) {
         bf16_t* orow = dqkv + (size_t)(b * N + qi) * ld + head * 64;
@@ -289,15 +359,61 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16_t* __restri
 }
 
 // ============================================================================ dK, dV
+// LDS stage = Q 8 KiB | dO 8 KiB | -lse 256 B | delta 256 B
+constexpr int kDkdvStage = 8192 * 2 + 512;
+
+template <int QOFF>
+__device__ __forceinline__ void dkdv_subtile(const AS3 char* lds, const FragAddr& fa, const bf16x8 (&kf)[4], const bf16x8 (&vf)[4],
+                                             f32x16& dk0, f32x16& dk1, f32x16& dv0, f32x16& dv1, int stat_off, int q0, int N,
+                                             int h, float scale_log2) {
+    constexpr int DOFF = QOFF + 8192;
+    f32x16 s = zero16(), dp = zero16();
+#pragma unroll
+    for (int stp = 0; stp < 4; ++stp) {
+        s = MFMA32(lds_rows<QOFF>(lds, fa.rows[stp]), kf[stp], s);
+        dp = MFMA32(lds_rows<DOFF>(lds, fa.rows[stp]), vf[stp], dp);
+    }
+    // rows of s/dp are queries: registers 4g..4g+3 <-> queries q0 + 8 g + 4 h + 0..3 (lse / delta broadcast from LDS)
+    const AS3 float* stl = reinterpret_cast<const AS3 float*>(lds + stat_off) + 4 * h;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const f32x4 ls = *reinterpret_cast<const AS3 f32x4*>(stl + 8 * g);
+        const f32x4 de = *reinterpret_cast<const AS3 f32x4*>(stl + 64 + 8 * g);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int r = 4 * g + e;
+            const float p = fast_exp2(fmaf(s[r], scale_log2, -ls[e]));
+            s[r] = p;
+            dp[r] = p * (dp[r] - de[e]);
+        }
+    }
+    if (q0 + 32 > N) {
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            if (q0 + acc_row(r, h) >= N) { s[r] = 0.f; dp[r] = 0.f; }
+    }
+    const bf16x8 p0 = acc_to_frag(s, 0), p1 = acc_to_frag(s, 1);
+    const bf16x8 d0 = acc_to_frag(dp, 0), d1 = acc_to_frag(dp, 1);
+    dv0 = MFMA32(lds_tr<DOFF>(lds, fa.tr[0][0], fa.tr[0][1]), p0, dv0);
+    dv1 = MFMA32(lds_tr<DOFF>(lds, fa.tr[1][0], fa.tr[1][1]), p0, dv1);
+    dk0 = MFMA32(lds_tr<QOFF>(lds, fa.tr[0][0], fa.tr[0][1]), d0, dk0);
+    dk1 = MFMA32(lds_tr<QOFF>(lds, fa.tr[1][0], fa.tr[1][1]), d0, dk1);
+    dv0 = MFMA32(lds_tr<DOFF + 2048>(lds, fa.tr[0][0], fa.tr[0][1]), p1, dv0);
+    dv1 = MFMA32(lds_tr<DOFF + 2048>(lds, fa.tr[1][0], fa.tr[1][1]), p1, dv1);
+    dk0 = MFMA32(lds_tr<QOFF + 2048>(lds, fa.tr[0][0], fa.tr[0][1]), d1, dk0);
+    dk1 = MFMA32(lds_tr<QOFF + 2048>(lds, fa.tr[1][0], fa.tr[1][1]), d1, dk1);
+}
+
 // grid (ceil(N/128), B*H); wave w owns 32 keys; loops over query tiles (Q, dO, lse, delta staged)
-// LDS stage = Q 8 KiB | dO 8 KiB | lse 256 B | delta 256 B
-__global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dctx,
-                                                            const float* __restrict__ lse, const float* __restrict__ delta,
-                                                            bf16_t* __restrict__ dqkv, int N, int H, int D,
-                                                            uint32_t qkv_bytes, uint32_t dctx_bytes, uint32_t stat_bytes,
-                                                            float scale, float scale_log2) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dctx,
+                                                               const float* __restrict__ lse, const float* __restrict__ delta,
+                                                               bf16_t* __restrict__ dqkv, int N, int H, int D,
+                                                               uint32_t qkv_bytes, uint32_t dctx_bytes, uint32_t stat_bytes,
+                                                               float scale, float scale_log2) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int STG = 8192 * 2 + 512;
+    const AS3 char* lds = (const AS3 char*)smem;
+    constexpr int STG = kDkdvStage;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int bh = blockIdx.y, b = bh / H, head = bh % H;
@@ -309,6 +425,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const bf16_t* __rest
     const __amdgpu_buffer_rsrc_t rd = make_rsrc(dctx, dctx_bytes);
     const __amdgpu_buffer_rsrc_t rl = make_rsrc(lse, stat_bytes);
     const __amdgpu_buffer_rsrc_t re = make_rsrc(delta, stat_bytes);
+    const FragAddr fa = make_frag_addr(lane);
 
     bf16x8 kf[4], vf[4];   // B operands of S = Q K^T and dP = dO V^T
     {
@@ -320,7 +437,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const bf16_t* __rest
 
     const int nqt = (N + 63) >> 6;
     const int qrow0 = b * N;
-    auto stage = [&](int qt, char* dst) {
+    auto issue = [&](int qt, int stage) {
+        char* dst = smem + stage * STG;
         stage64(rq, qrow0 + qt * 64, ld, head * 64, dst, wave, lane);
         stage64(rd, qrow0 + qt * 64, D, head * 64, dst + 8192, wave, lane);
         if (wave == 0)
@@ -328,51 +446,20 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const bf16_t* __rest
         if (wave == 1)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(re, LDS_PTR(dst + 16384 + 256), 4, (uint32_t)(((size_t)bh * N + qt * 64 + lane) * 4), 0, 0, 0);
     };
-    stage(0, smem);
-    for (int qt = 0; qt < nqt; ++qt) {
+    issue(0, 0);
+    for (int qt = 0; qt < nqt; qt += 2) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (qt + 1 < nqt) stage(qt + 1, smem + ((qt + 1) & 1) * STG);
-        const char* ql = smem + (qt & 1) * STG;
-        const char* dl = ql + 8192;
-        const __attribute__((address_space(3))) float* stl =
-            (const __attribute__((address_space(3))) float*)((const __attribute__((address_space(3))) char*)(ql) + 16384);
-#pragma unroll
-        for (int sub = 0; sub < 2; ++sub) {
-            const int q0 = qt * 64 + sub * 32;
-            if (q0 >= N) break;
-            f32x16 s = zero16(), dp = zero16();
-#pragma unroll
-            for (int st = 0; st < 4; ++st) {
-                s = MFMA32(frag_rows(ql, sub * 32, st, lane), kf[st], s);
-                dp = MFMA32(frag_rows(dl, sub * 32, st, lane), vf[st], dp);
-            }
-            // rows of s/dp are queries: registers 4g..4g+3 <-> queries q0 + 8 g + 4 h + 0..3
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int qq = sub * 32 + 8 * g + 4 * h;
-                const f32x4 ls = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(stl + qq);
-                const f32x4 de = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(stl + 64 + qq);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int r = 4 * g + e;
-                    float p = exp2f(s[r] * scale_log2 - ls[e]);
-                    float ds = p * (dp[r] - de[e]);
-                    if (q0 + 32 > N && q0 + 8 * g + 4 * h + e >= N) { p = 0.f; ds = 0.f; }
-                    s[r] = p;
-                    dp[r] = ds;
-                }
-            }
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const bf16x8 pf = acc_to_frag(s, ks);
-                const bf16x8 df = acc_to_frag(dp, ks);
-                dv0 = MFMA32(frag_tr(dl, sub * 32, ks, 0, lane), pf, dv0);
-                dv1 = MFMA32(frag_tr(dl, sub * 32, ks, 32, lane), pf, dv1);
-                dk0 = MFMA32(frag_tr(ql, sub * 32, ks, 0, lane), df, dk0);
-                dk1 = MFMA32(frag_tr(ql, sub * 32, ks, 32, lane), df, dk1);
-            }
-        }
+        if (qt + 1 < nqt) issue(qt + 1, 1);
+        dkdv_subtile<0>(lds, fa, kf, vf, dk0, dk1, dv0, dv1, 16384, qt * 64, N, h, scale_log2);
+        if (qt * 64 + 32 < N) dkdv_subtile<4096>(lds, fa, kf, vf, dk0, dk1, dv0, dv1, 16384 + 128, qt * 64 + 32, N, h, scale_log2);
+        if (qt + 1 >= nqt) break;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (qt + 2 < nqt) issue(qt + 2, 0);
+        dkdv_subtile<STG>(lds, fa, kf, vf, dk0, dk1, dv0, dv1, STG + 16384, qt * 64 + 64, N, h, scale_log2);
+        if (qt * 64 + 96 < N)
+            dkdv_subtile<STG + 4096>(lds, fa, kf, vf, dk0, dk1, dv0, dv1, STG + 16384 + 128, qt * 64 + 96, N, h, scale_log2);
     }
     if (ki < N) {
         bf16_t* krow = dqkv + (size_t)(b * N + ki) * ld + D + head * 64;
@@ -417,7 +504,7 @@ int launch_attn_bwd(const bf16_t* qkv, const bf16_t* ctx, const bf16_t* dctx, co
         hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, dctx, ctx, delta, B, N, H, D);
     }
     dim3 grid((N + 127) / 128, B * H);
-    hipLaunchKernelGGL(attn_bwd_dkdv_kernel, grid, dim3(256), 2 * (16384 + 512), stream, qkv, dctx, lse, delta, dqkv, N, H, D,
+    hipLaunchKernelGGL(attn_bwd_dkdv_kernel, grid, dim3(256), 2 * kDkdvStage, stream, qkv, dctx, lse, delta, dqkv, N, H, D,
                        (uint32_t)bytes, (uint32_t)((size_t)B * N * D * 2), (uint32_t)((size_t)B * H * N * 4), scale, scale_log2);
     hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 32768, stream, qkv, dctx, lse, delta, dqkv, N, H, D,
                        (uint32_t)bytes, scale, scale_log2);

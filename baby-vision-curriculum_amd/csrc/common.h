@@ -17,8 +17,12 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
     __bf16 b = (__bf16)f;
     return *reinterpret_cast<bf16_t*>(&b);
 }
+// two floats -> packed bf16x2 in ONE v_cvt_pk_bf16_f32 (separate scalar casts cost 4 VALU per pair)
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
 __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
-    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+    const bf16x2_t b = __builtin_convertvector(f32x2{lo, hi}, bf16x2_t);
+    return *reinterpret_cast<const uint32_t*>(&b);
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -36,10 +36,29 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
-// exact-erf GELU (the reference's hidden_act="gelu", HF:299-308) and its derivative
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// exact-erf GELU (the reference's hidden_act="gelu", HF:299-308) and its derivative.
+// erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, far below the bf16 rounding of the result): one v_rcp, one
+// v_exp and five FMAs instead of libm erff's ~40 VALU - the GELU epilogues were doubling the fc1 / dX-fc2 GEMMs.
+// gelu and gelu' share the exponential: with z = x / sqrt(2),  exp(-z^2) = exp(-x^2 / 2).
+struct GeluParts { float erf_abs, e; };   // erf(|z|) and exp(-x^2/2)
+__device__ __forceinline__ GeluParts gelu_parts(float x) {
+    const float az = fabsf(x) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, az, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    p *= t;
+    const float e = __builtin_amdgcn_exp2f(x * x * -0.72134752044448170f);   // exp(-x^2/2) = 2^(-x^2/2 * log2 e)
+    return GeluParts{fmaf(-p, e, 1.0f), e};
+}
+__device__ __forceinline__ float gelu_f(float x) {
+    const GeluParts g = gelu_parts(x);
+    return 0.5f * x * (1.0f + copysignf(g.erf_abs, x));
+}
 __device__ __forceinline__ float dgelu_f(float x) {
-    return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.39894228040143268f * __expf(-0.5f * x * x);
+    const GeluParts g = gelu_parts(x);
+    return fmaf(x * 0.39894228040143268f, g.e, 0.5f * (1.0f + copysignf(g.erf_abs, x)));
 }
 
 // buffer resource over [base, base+bytes): out-of-range lanes of a buffer load return 0

@@ -14,6 +14,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -177,8 +178,17 @@ struct bvc_ctx {
     int npartial = 0;
     // backward scratch (sized for the larger of encoder / decoder)
     float *dres_enc, *dres_dec;
-    bf16_t *dyb, *dhb, *dln, *dctx, *dqkv, *dh, *de2d;
+    // dY operands of the weight-gradient products are multi-buffered: the grouped dW launch of backward step s runs
+    // on the side stream while the main stream already works on step s+1 (buffers are reused at step s+2 / s+3)
+    bf16_t *dyb[3], *dhb[2], *dqkv[2], *dh[2];
+    bf16_t *dln, *dctx, *de2d;
     float* delta;
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
+    bool overlap = true;
+    int seq = 0;                       // backward step counter of the current call
+    bool join_pending[2] = {false, false};
+    int64_t pend_lo[2], pend_hi[2];    // gradient range reported once the side stream's launch is fenced
     float* ln_part;    // per-workgroup LayerNorm parameter-gradient partials
 };
 
@@ -286,48 +296,81 @@ int layer_forward(bvc_ctx* c, Stack& s, int li, const LayerOff& o, float* x_in_e
     return BVC_OK;
 }
 
-// dres (f32 [M][D]) holds d/d(layer output) on entry and d/d(layer input) on exit; dyb is its bf16 copy.
-int layer_backward(bvc_ctx* c, Stack& s, int li, const LayerOff& o, const float* x_in, float* dres, float* G, int B, int N, hipStream_t st) {
+// Fence a side-stream weight-gradient launch into the main stream and report its gradient range.
+int join_side(bvc_ctx* c, int parity, hipStream_t st, bvc_bucket_fn on_bucket, void* user) {
+    if (!c->join_pending[parity]) return BVC_OK;
+    BVC_CHECK_HIP(hipStreamWaitEvent(st, c->ev_join[parity], 0));
+    c->join_pending[parity] = false;
+    if (on_bucket) on_bucket(c->pend_lo[parity], c->pend_hi[parity] - c->pend_lo[parity], user);
+    return BVC_OK;
+}
+
+// dres (f32 [M][D]) holds d/d(layer output) on entry and d/d(layer input) on exit; dyb[seq % 3] is its bf16 copy.
+// The four weight gradients (+ bias gradients) of the layer are one grouped launch on the side stream, overlapping the
+// next layer's dX chain; its gradient range [o.ln1w, o.end) is reported when that launch has been fenced (two steps later).
+int layer_backward(bvc_ctx* c, Stack& s, int li, const LayerOff& o, const float* x_in, float* dres, float* G, int B, int N,
+                   hipStream_t st, bvc_bucket_fn on_bucket, void* user) {
     LayerAct& a = s.act[li];
     const int D = s.D, I = s.I, M = B * N;
     const float* P = c->params;
     const bf16_t* W = c->wbf;
+    const int q = c->seq, par = q & 1;
+    bf16_t* dyb = c->dyb[q % 3];
+    bf16_t* dyb_next = c->dyb[(q + 1) % 3];
+    bf16_t *dh = c->dh[par], *dhb = c->dhb[par], *dqkv = c->dqkv[par];
+    // the buffers of this parity were last read by the side launch of step q-2
+    TRY(join_side(c, par, st, on_bucket, user));
     // MLP
     {
-        GemmProblem p = gemm(c->dyb, (size_t)M * D, D, W + o.w2, (size_t)D * I, I, M, I, D, EPI_DGELU, c->dh, I);
+        GemmProblem p = gemm(dyb, (size_t)M * D, D, W + o.w2, (size_t)D * I, I, M, I, D, EPI_DGELU, dh, I);
         p.aux = a.pre; p.ldaux = I;
         TRY(launch_gemm(&p, 1, GEMM_NN, -1, st));
     }
     {
-        GemmProblem p = gemm(c->dh, (size_t)M * I, I, W + o.w1, (size_t)I * D, D, M, D, I, EPI_BF16, c->dln, D);
+        GemmProblem p = gemm(dh, (size_t)M * I, I, W + o.w1, (size_t)I * D, D, M, D, I, EPI_BF16, c->dln, D);
         TRY(launch_gemm(&p, 1, GEMM_NN, -1, st));
     }
-    TRY(launch_ln_bwd(c->dln, a.h, identity_rows(), a.mean2, a.rstd2, P + o.ln2w, dres, 1, c->dhb, G + o.ln2w, G + o.ln2b, c->ln_part, M, D, st));
+    TRY(launch_ln_bwd(c->dln, a.h, identity_rows(), a.mean2, a.rstd2, P + o.ln2w, dres, 1, dhb, G + o.ln2w, G + o.ln2b, c->ln_part, M, D, st));
     // attention
     {
-        GemmProblem p = gemm(c->dhb, (size_t)M * D, D, W + o.wo, (size_t)D * D, D, M, D, D, EPI_BF16, c->dctx, D);
+        GemmProblem p = gemm(dhb, (size_t)M * D, D, W + o.wo, (size_t)D * D, D, M, D, D, EPI_BF16, c->dctx, D);
         TRY(launch_gemm(&p, 1, GEMM_NN, -1, st));
     }
-    TRY(launch_attn_bwd(a.qkv, a.ctx, c->dctx, a.lse, c->delta, c->dqkv, B, N, s.H, st));
+    TRY(launch_attn_bwd(a.qkv, a.ctx, c->dctx, a.lse, c->delta, dqkv, B, N, s.H, st));
     {
-        GemmProblem p = gemm(c->dqkv, (size_t)M * 3 * D, 3 * D, W + o.wqkv, (size_t)3 * D * D, D, M, D, 3 * D, EPI_BF16, c->dln, D);
+        GemmProblem p = gemm(dqkv, (size_t)M * 3 * D, 3 * D, W + o.wqkv, (size_t)3 * D * D, D, M, D, 3 * D, EPI_BF16, c->dln, D);
         TRY(launch_gemm(&p, 1, GEMM_NN, -1, st));
     }
-    // the four weight gradients of the layer as one grouped launch:  dW = dY^T X
+    // the four weight gradients of the layer as one grouped launch:  dW = dY^T X,  db = column sums of dY
+    hipStream_t ws = st;
+    if (c->overlap) {
+        BVC_CHECK_HIP(hipEventRecord(c->ev_fork, st));
+        BVC_CHECK_HIP(hipStreamWaitEvent(c->side, c->ev_fork, 0));
+        ws = c->side;
+    }
     {
         GemmProblem g[4];
-        g[0] = gemm(c->dyb, (size_t)M * D, D, a.act, (size_t)M * I, I, D, I, M, EPI_F32, G + o.w2, I);
-        g[1] = gemm(c->dh, (size_t)M * I, I, a.ln2o, (size_t)M * D, D, I, D, M, EPI_F32, G + o.w1, D);
-        g[2] = gemm(c->dhb, (size_t)M * D, D, a.ctx, (size_t)M * D, D, D, D, M, EPI_F32, G + o.wo, D);
-        g[3] = gemm(c->dqkv, (size_t)M * 3 * D, 3 * D, a.ln1o, (size_t)M * D, D, 3 * D, D, M, EPI_F32, G + o.wqkv, D);
+        g[0] = gemm(dyb, (size_t)M * D, D, a.act, (size_t)M * I, I, D, I, M, EPI_F32, G + o.w2, I);
+        g[1] = gemm(dh, (size_t)M * I, I, a.ln2o, (size_t)M * D, D, I, D, M, EPI_F32, G + o.w1, D);
+        g[2] = gemm(dhb, (size_t)M * D, D, a.ctx, (size_t)M * D, D, D, D, M, EPI_F32, G + o.wo, D);
+        g[3] = gemm(dqkv, (size_t)M * 3 * D, 3 * D, a.ln1o, (size_t)M * D, D, 3 * D, D, M, EPI_F32, G + o.wqkv, D);
         g[0].rowsum = G + o.b2;     // bias gradients ride along as one extra MFMA column each
         g[1].rowsum = G + o.b1;
         g[2].rowsum = G + o.bo;
         g[3].rowsum = G + o.bqkv;
         const int tile = plan_dw(g, 4);
-        TRY(launch_gemm(g, 4, GEMM_TN, tile, st));
+        TRY(launch_gemm(g, 4, GEMM_TN, tile, ws));
     }
-    TRY(launch_ln_bwd(c->dln, x_in, identity_rows(), a.mean1, a.rstd1, P + o.ln1w, dres, 1, c->dyb, G + o.ln1w, G + o.ln1b, c->ln_part, M, D, st));
+    TRY(launch_ln_bwd(c->dln, x_in, identity_rows(), a.mean1, a.rstd1, P + o.ln1w, dres, 1, dyb_next, G + o.ln1w, G + o.ln1b, c->ln_part, M, D, st));
+    if (c->overlap) {
+        BVC_CHECK_HIP(hipEventRecord(c->ev_join[par], c->side));
+        c->join_pending[par] = true;
+        c->pend_lo[par] = o.ln1w;
+        c->pend_hi[par] = o.end;
+    } else if (on_bucket) {
+        on_bucket(o.ln1w, o.end - o.ln1w, user);
+    }
+    c->seq = q + 1;
     return BVC_OK;
 }
 
@@ -364,6 +407,9 @@ int bvc_videomae_param_info(const bvc_videomae_config* cfg, int index, char* nam
 
 void bvc_videomae_destroy(bvc_ctx* c) {
     if (!c) return;
+    if (c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamDestroy(c->side); }
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    for (int i = 0; i < 2; ++i) if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
     for (void* p : c->allocs) (void)hipFree(p);
     delete c;
 }
@@ -412,16 +458,28 @@ int bvc_videomae_create(const bvc_videomae_config* cfg, int max_batch, int num_m
     A(dev_alloc(c, &c->dres_enc, Mv * D));
     A(dev_alloc(c, &c->dres_dec, Md * Dd));
     const size_t MD = std::max(Mv * D, Md * Dd), MI = std::max(Mv * I, Md * Id);
-    A(dev_alloc(c, &c->dyb, MD));
-    A(dev_alloc(c, &c->dhb, MD));
+    for (int i = 0; i < 3; ++i) A(dev_alloc(c, &c->dyb[i], MD));
+    for (int i = 0; i < 2; ++i) {
+        A(dev_alloc(c, &c->dhb[i], MD));
+        A(dev_alloc(c, &c->dqkv[i], 3 * MD));
+        A(dev_alloc(c, &c->dh[i], MI));
+    }
     A(dev_alloc(c, &c->dln, MD));
     A(dev_alloc(c, &c->dctx, MD));
-    A(dev_alloc(c, &c->dqkv, 3 * MD));
-    A(dev_alloc(c, &c->dh, MI));
     A(dev_alloc(c, &c->de2d, Mv * Dd));
     A(dev_alloc(c, &c->delta, std::max(B * H * c->nvis, B * Hd * c->L)));
     A(dev_alloc(c, &c->ln_part, std::max(ln_bwd_workspace_floats_upto((int)Mv, D), ln_bwd_workspace_floats_upto((int)Md, Dd))));
 #undef A
+    // Measured on MI355X (B=16): running the grouped dW launch on a side stream next to the dX chain gains nothing
+    // (1398 vs 1419 clips/s) - each GEMM already holds all of a CU's LDS - so it is opt-in for experiments.
+    c->overlap = getenv("BVC_DW_OVERLAP") != nullptr;
+    if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_join[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_join[1], hipEventDisableTiming) != hipSuccess) {
+        set_error("create: side stream / events");
+        return fail(BVC_ERR_HIP);
+    }
     std::vector<float> tab;
     sinusoid(tab, c->L, D);
     if (hipMemcpy(c->pos_enc, tab.data(), tab.size() * 4, hipMemcpyHostToDevice) != hipSuccess) { set_error("create: pos upload failed"); return fail(BVC_ERR_HIP); }
@@ -500,6 +558,8 @@ int bvc_videomae_backward(bvc_ctx* c, const float* grad_loss, float* G, bvc_buck
     const bf16_t* W = c->wbf;
     const float* params = c->params;
     auto bucket = [&](int64_t lo, int64_t hi) { if (on_bucket) on_bucket(lo, hi - lo, user); };
+    c->seq = 0;
+    c->join_pending[0] = c->join_pending[1] = false;
 
     BVC_CHECK_HIP(hipMemsetAsync(G, 0, (size_t)L.total * 4, st));
     // d loss / d logits = (2 / (Mm P)) * diff * grad_loss  - folded into alpha of the three head products
@@ -518,14 +578,13 @@ int bvc_videomae_backward(bvc_ctx* c, const float* grad_loss, float* G, bvc_buck
     }
     // visible rows of the decoder stream receive no gradient from the head
     BVC_CHECK_HIP(hipMemsetAsync(c->dres_dec, 0, (size_t)Md * Dd * 4, st));
-    BVC_CHECK_HIP(hipMemsetAsync(c->dyb, 0, (size_t)Md * Dd * 2, st));
+    BVC_CHECK_HIP(hipMemsetAsync(c->dyb[0], 0, (size_t)Md * Dd * 2, st));
     const RowMap tail{nmask, Lq, nvis};
-    TRY(launch_ln_bwd(c->dln, c->dec.x_out, tail, c->meanf, c->rstdf, params + L.norm_w, c->dres_dec, 0, c->dyb,
+    TRY(launch_ln_bwd(c->dln, c->dec.x_out, tail, c->meanf, c->rstdf, params + L.norm_w, c->dres_dec, 0, c->dyb[0],
                       G + L.norm_w, G + L.norm_b, c->ln_part, Mm, Dd, st));
     bucket(L.norm_w, L.total);
     for (int i = c->dec.nlayers - 1; i >= 0; --i) {
-        TRY(layer_backward(c, c->dec, i, L.dec[i], c->dec.act[i].x_in, c->dres_dec, G, B, Lq, st));
-        bucket(L.dec[i].ln1w, L.dec[i].end);
+        TRY(layer_backward(c, c->dec, i, L.dec[i], c->dec.act[i].x_in, c->dres_dec, G, B, Lq, st, on_bucket, user));
     }
     // decoder input: mask token, encoder_to_decoder
     TRY(launch_colsum_f32(c->dres_dec, tail, Mm, Dd, G + L.mask_token, st));
@@ -538,21 +597,23 @@ int bvc_videomae_backward(bvc_ctx* c, const float* grad_loss, float* G, bvc_buck
     }
     {
         GemmProblem p = gemm(c->de2d, (size_t)Mv * Dd, Dd, W + L.e2d_w, (size_t)Dd * D, D, Mv, D, Dd, EPI_F32_BF16, c->dres_enc, D);
-        p.C2 = c->dyb;
+        p.C2 = c->dyb[c->seq % 3];   // last read (as a dW operand) by backward step seq-3, fenced since
         TRY(launch_gemm(&p, 1, GEMM_NN, -1, st));
     }
     bucket(L.e2d_w, L.dec.front().ln1w);
     for (int i = c->enc.nlayers - 1; i >= 0; --i) {
-        TRY(layer_backward(c, c->enc, i, L.enc[i], c->enc.act[i].x_in, c->dres_enc, G, B, nvis, st));
-        bucket(L.enc[i].ln1w, L.enc[i].end);
+        TRY(layer_backward(c, c->enc, i, L.enc[i], c->enc.act[i].x_in, c->dres_enc, G, B, nvis, st, on_bucket, user));
     }
     // patch embedding: weight and bias only (pixels need no gradient)
     {
-        GemmProblem p = gemm(c->dyb, (size_t)Mv * D, D, c->Ape, (size_t)Mv * c->Kp, c->Kp, D, c->Kp, Mv, EPI_F32, G + L.pe_w, c->Kp);
+        GemmProblem p = gemm(c->dyb[c->seq % 3], (size_t)Mv * D, D, c->Ape, (size_t)Mv * c->Kp, c->Kp, D, c->Kp, Mv, EPI_F32, G + L.pe_w, c->Kp);
         p.rowsum = G + L.pe_b;
         const int tile = plan_dw(&p, 1);
         TRY(launch_gemm(&p, 1, GEMM_TN, tile, st));
     }
+    // fence the last side-stream launches (older one first so ranges keep arriving tail-first)
+    TRY(join_side(c, c->seq & 1, st, on_bucket, user));
+    TRY(join_side(c, (c->seq + 1) & 1, st, on_bucket, user));
     bucket(0, L.enc.front().ln1w);
     return BVC_OK;
 }

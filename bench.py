@@ -114,7 +114,8 @@ def main():
         bool_masked = np.zeros((B, 1568))
         for i in range(B):
             bool_masked[i, :] = mask_gen()
-        bool_masked_pos = torch.from_numpy(bool_masked).bool().to(dev)
+        # pinned + non_blocking: a pageable .to(device) makes the host wait for the stream, so it could not run ahead
+        bool_masked_pos = torch.from_numpy(bool_masked).bool().pin_memory().to(dev, non_blocking=True)
         opt.zero_grad()
         with torch.autocast("cuda", dtype=torch.bfloat16):
             out = xmodel(clips, bool_masked_pos=bool_masked_pos)

@@ -28,7 +28,9 @@ for step in "$@"; do
     bench) run bench 400 python bench.py ;;
     bench32) run bench32 400 python bench.py --batch 32 --no-cpu-baseline ;;
     benchq) run benchq 300 python bench.py --no-cpu-baseline ;;
+    benchov) BVC_DW_OVERLAP=1 run benchov 300 python bench.py --no-cpu-baseline ;;
     micro) run micro 400 python tools/microbench.py ;;
+    probe) run probe 300 python tools/gemm_probe.py ;;
     prof)  rm -rf $OUT/prof; cd /tmp
            run prof 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline
            cd $R

@@ -21,6 +21,8 @@
 
 namespace bvc {
 
+#define AS3 __attribute__((address_space(3)))
+
 struct GemmGroup {
     int nprob;
     int tile_start[kMaxGroup + 1];
@@ -200,86 +202,122 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmGroup g) {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // LDS is reused by the loss epilogue
 
     // ------------------------------------------------------------------ epilogue
+    // The MFMA fragment layout gives each lane 4 columns of one row: stored directly, a wave touches 16 rows x 32 B
+    // per instruction and the write path reaches only ~2.2 TB/s (measured).  Instead every wave parks its f32 tile in
+    // LDS (free after the K loop; XOR-swizzled 16-B units, no bank conflicts) and re-reads it row-major, so each lane
+    // owns 8 consecutive columns and every global load / store of the epilogue is a full 128-B line per 8 lanes.
     const int epi = p.epi;
     const float alpha = p.alpha_dev ? p.alpha * p.alpha_dev[0] : p.alpha;
     float sumsq = 0.f;
     const bool atomic = p.split_k > 1;
+    constexpr int UNITS = WN / 4;                       // 16-B units per tile row
+    AS3 char* wl = (AS3 char*)smem + wave * (WM * WN * 4);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int row = 16 * i + (lane & 15);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int unit = (4 * j + (lane >> 4)) ^ (row & (UNITS - 1));
+            *reinterpret_cast<AS3 f32x4*>(wl + row * (WN * 4) + unit * 16) = acc[i][j];
+        }
+    }
     if (nt > 0 || !atomic) {
+        constexpr int CPR = WN / 8;                     // 8-column chunks per row
+        constexpr int NCH = WM * WN / 8 / 64;           // chunks per lane
+#pragma unroll 2
+        for (int it = 0; it < NCH; ++it) {
+            const int id = it * 64 + lane;
+            const int row = id / CPR, cc = id % CPR;
+            const int m = m0 + wm * WM + row;
+            const int n = n0 + wn * WN + cc * 8;
+            const f32x4 lo = *reinterpret_cast<const AS3 f32x4*>(wl + row * (WN * 4) + (((2 * cc) ^ (row & (UNITS - 1))) << 4));
+            const f32x4 hi = *reinterpret_cast<const AS3 f32x4*>(wl + row * (WN * 4) + (((2 * cc + 1) ^ (row & (UNITS - 1))) << 4));
+            if (m >= p.M || n >= p.N) continue;
+            float v[8] = {lo[0] * alpha, lo[1] * alpha, lo[2] * alpha, lo[3] * alpha,
+                          hi[0] * alpha, hi[1] * alpha, hi[2] * alpha, hi[3] * alpha};
+            if (p.bias && (!atomic || split == 0)) {
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + n);
+                const f32x4 b1 = *reinterpret_cast<const f32x4*>(p.bias + n + 4);
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int m = m0 + wm * WM + 16 * i + (lane & 15);
+                for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
+            }
+            const size_t idx = (size_t)m * p.ldc + n;
+            auto store_f32 = [&](float* dst) {
+                *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
+                *reinterpret_cast<f32x4*>(dst + 4) = f32x4{v[4], v[5], v[6], v[7]};
+            };
+            auto store_bf16 = [&](void* base, size_t at, const float* w) {
+                *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(base) + at) =
+                    uint4{pack2bf(w[0], w[1]), pack2bf(w[2], w[3]), pack2bf(w[4], w[5]), pack2bf(w[6], w[7])};
+            };
+            auto add8 = [&](const float* src) {
+                const f32x4 a0 = *reinterpret_cast<const f32x4*>(src);
+                const f32x4 a1 = *reinterpret_cast<const f32x4*>(src + 4);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int n = n0 + wn * WN + 16 * j + 4 * (lane >> 4);
-                if (m >= p.M || n >= p.N) continue;
-                f32x4 v = acc[i][j] * alpha;
-                if (p.bias && (!atomic || split == 0)) {
-                    const f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + n);
-                    v += b;
-                }
-                const size_t idx = (size_t)m * p.ldc + n;
-                switch (epi) {
-                    case EPI_F32: {
-                        float* c = reinterpret_cast<float*>(p.C) + idx;
-                        if (atomic) {
+                for (int e = 0; e < 4; ++e) { v[e] += a0[e]; v[4 + e] += a1[e]; }
+            };
+            switch (epi) {
+                case EPI_F32: {
+                    float* c = reinterpret_cast<float*>(p.C) + idx;
+                    if (atomic) {
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) atomicAdd(c + e, v[e]);
-                        } else {
-                            *reinterpret_cast<f32x4*>(c) = v;
-                        }
-                    } break;
-                    case EPI_BF16: {
-                        uint2 o = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
-                        *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + idx) = o;
-                    } break;
-                    case EPI_GELU: {
-                        uint2 o = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
-                        *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + idx) = o;
-                        uint2 a = {pack2bf(gelu_f(v[0]), gelu_f(v[1])), pack2bf(gelu_f(v[2]), gelu_f(v[3]))};
-                        *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C2) + idx) = a;
-                    } break;
-                    case EPI_RESID: {
-                        float* c = reinterpret_cast<float*>(p.C) + idx;
-                        if (atomic) {
+                        for (int e = 0; e < 8; ++e) atomicAdd(c + e, v[e]);
+                    } else {
+                        store_f32(c);
+                    }
+                } break;
+                case EPI_BF16: store_bf16(p.C, idx, v); break;
+                case EPI_GELU: {
+                    store_bf16(p.C, idx, v);
+                    float a[8];
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) atomicAdd(c + e, v[e]);
-                        } else {
-                            const f32x4 r = *reinterpret_cast<const f32x4*>(p.resid + idx);
-                            *reinterpret_cast<f32x4*>(c) = r + v;
-                        }
-                    } break;
-                    case EPI_POS: {
-                        const f32x4 pe = *reinterpret_cast<const f32x4*>(p.pos + (size_t)p.rowtok[m] * p.N + n);
-                        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + idx) = v + pe;
-                    } break;
-                    case EPI_E2D: {
-                        const f32x4 pe = *reinterpret_cast<const f32x4*>(p.pos + (size_t)p.rowtok[m] * p.N + n);
-                        const size_t orow = (size_t)(m / p.rin) * p.rout + (m % p.rin);
-                        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + orow * p.ldc + n) = v + pe;
-                    } break;
-                    case EPI_LOSS: {
-                        if (p.C2) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C2) + idx) = v;
-                        const f32x4 lab = *reinterpret_cast<const f32x4*>(p.labels + idx);
-                        const f32x4 d = v - lab;
-                        sumsq += d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3];
-                        uint2 o = {pack2bf(d[0], d[1]), pack2bf(d[2], d[3])};
-                        *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + idx) = o;
-                    } break;
-                    case EPI_DGELU: {
-                        const uint2 a = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(p.aux) + (size_t)m * p.ldaux + n);
-                        const float x0 = __uint_as_float(a.x << 16), x1 = __uint_as_float(a.x & 0xffff0000u);
-                        const float x2 = __uint_as_float(a.y << 16), x3 = __uint_as_float(a.y & 0xffff0000u);
-                        uint2 o = {pack2bf(v[0] * dgelu_f(x0), v[1] * dgelu_f(x1)),
-                                   pack2bf(v[2] * dgelu_f(x2), v[3] * dgelu_f(x3))};
-                        *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + idx) = o;
-                    } break;
-                    case EPI_F32_BF16: {
-                        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + idx) = v;
-                        uint2 o = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
-                        *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C2) + idx) = o;
-                    } break;
-                    default: break;
-                }
+                    for (int e = 0; e < 8; ++e) a[e] = gelu_f(v[e]);
+                    store_bf16(p.C2, idx, a);
+                } break;
+                case EPI_RESID: {
+                    float* c = reinterpret_cast<float*>(p.C) + idx;
+                    if (atomic) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) atomicAdd(c + e, v[e]);
+                    } else {
+                        add8(p.resid + idx);
+                        store_f32(c);
+                    }
+                } break;
+                case EPI_POS: {
+                    add8(p.pos + (size_t)p.rowtok[m] * p.N + n);
+                    store_f32(reinterpret_cast<float*>(p.C) + idx);
+                } break;
+                case EPI_E2D: {
+                    add8(p.pos + (size_t)p.rowtok[m] * p.N + n);
+                    const size_t orow = (size_t)(m / p.rin) * p.rout + (m % p.rin);
+                    store_f32(reinterpret_cast<float*>(p.C) + orow * p.ldc + n);
+                } break;
+                case EPI_LOSS: {
+                    if (p.C2) store_f32(reinterpret_cast<float*>(p.C2) + idx);
+                    const f32x4 l0 = *reinterpret_cast<const f32x4*>(p.labels + idx);
+                    const f32x4 l1 = *reinterpret_cast<const f32x4*>(p.labels + idx + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v[e] -= l0[e]; v[4 + e] -= l1[e]; }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) sumsq += v[e] * v[e];
+                    store_bf16(p.C, idx, v);
+                } break;
+                case EPI_DGELU: {
+                    const uint4 a = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(p.aux) + (size_t)m * p.ldaux + n);
+                    const uint32_t w[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[2 * e] *= dgelu_f(__uint_as_float(w[e] << 16));
+                        v[2 * e + 1] *= dgelu_f(__uint_as_float(w[e] & 0xffff0000u));
+                    }
+                    store_bf16(p.C, idx, v);
+                } break;
+                case EPI_F32_BF16: {
+                    store_f32(reinterpret_cast<float*>(p.C) + idx);
+                    store_bf16(p.C2, idx, v);
+                } break;
+                default: break;
             }
         }
     }
@@ -293,6 +331,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmGroup g) {
     if (epi == EPI_LOSS) {   // uniform per workgroup: deterministic per-tile partial of sum (logit-label)^2
         float* red = reinterpret_cast<float*>(smem);
         const float w = wave_sum(sumsq);
+        __syncthreads();   // every wave is done with its tile in LDS
         if (lane == 0) red[wave] = w;
         __syncthreads();
         if (tid == 0) p.partial[tile] = (red[0] + red[1]) + (red[2] + red[3]);
@@ -381,7 +420,7 @@ int launch_gemm(const GemmProblem* probs, int nprob, GemmLayout layout, int tile
         const GemmProblem& p = probs[i];
         BVC_REQUIRE(p.M > 0 && p.N > 0 && p.K > 0, "launch_gemm: empty problem %d (%d,%d,%d)", i, p.M, p.N, p.K);
         BVC_REQUIRE(p.N % 8 == 0, "launch_gemm: N=%d must be a multiple of 8", p.N);
-        BVC_REQUIRE(p.lda % 8 == 0 && p.ldb % 8 == 0 && p.ldc % 4 == 0, "launch_gemm: leading dims must be 16-byte aligned");
+        BVC_REQUIRE(p.lda % 8 == 0 && p.ldb % 8 == 0 && p.ldc % 8 == 0, "launch_gemm: leading dims must be multiples of 8");
         if (layout != GEMM_TN) BVC_REQUIRE(p.K % 64 == 0, "launch_gemm: K=%d must be a multiple of 64 for k-contiguous operands", p.K);
         if (layout == GEMM_TN) BVC_REQUIRE(p.M % 8 == 0, "launch_gemm: TN needs M %% 8 == 0 (M=%d)", p.M);
         BVC_REQUIRE(p.split_k >= 1, "launch_gemm: split_k must be >= 1");

@@ -25,13 +25,14 @@ import torch.nn as nn
 
 class DistributedDataParallel(nn.Module):
     def __init__(self, module, device_ids=None, output_device=None, find_unused_parameters=False,
-                 bucket_cap_mb=25.0, process_group=None, broadcast_parameters=True, **_ignored):
+                 bucket_cap_mb=25.0, process_group=None, broadcast_parameters=True, force_collectives=False, **_ignored):
         super().__init__()
         if not (dist.is_available() and dist.is_initialized()):
             raise RuntimeError("DistributedDataParallel needs an initialised process group (dist.init_process_group)")
         self.module = module
         self.process_group = process_group
         self.world_size = dist.get_world_size(process_group)
+        self.force_collectives = force_collectives   # issue the collectives even with one rank (tests)
         self.bucket_elems = int(bucket_cap_mb * 1024 * 1024 / 4)
         self._pending = None          # (lo, hi) coalesced range not yet reduced
         self._comm_stream = None
@@ -82,7 +83,7 @@ class DistributedDataParallel(nn.Module):
             self._pending = None
 
     def _reduce(self, lo, hi):
-        if self.world_size == 1:
+        if self.world_size == 1 and not self.force_collectives:
             self.reduced_ranges.append((lo, hi))
             return
         g = self.module.flat_grads()[lo:hi]

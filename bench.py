@@ -91,16 +91,21 @@ def main():
             raise SystemExit("launch with torch.distributed.run for --gpus > 1")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_ddp = world > 1 or bool(os.environ.get("BVC_FORCE_DDP"))   # the env switch exercises the RCCL path on one GPU
+    if use_ddp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world)   # "nccl" is RCCL on ROCm
 
-    ge.build()
+    if local_rank == 0:
+        ge.build()          # one builder per node; the other ranks wait for the library
+    if use_ddp:
+        dist.barrier()
     bvc = ge.load_package()
     torch.manual_seed(0)
     model = bvc.VideoMAEForPreTraining(bvc.VideoMAEConfig()).to(dev).train()
     model._ensure_flat(dev)
-    xmodel = bvc.DistributedDataParallel(model, device_ids=[local_rank]) if world > 1 else model
+    xmodel = bvc.DistributedDataParallel(model, device_ids=[local_rank], force_collectives=use_ddp) if use_ddp else model
     # same constructor arguments as the reference's torch.optim.SGD (pretrain_videomae.py:187-189); the update is one
     # HIP launch over the flat parameter buffer (--torch-sgd switches back to torch.optim.SGD)
     SGD = torch.optim.SGD if args.torch_sgd else bvc.optim.SGD
@@ -129,7 +134,7 @@ def main():
         step()
 
     def fence():
-        if world > 1:
+        if use_ddp:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -145,7 +150,7 @@ def main():
     gpu_ms = e0.elapsed_time(e1)    # HIP events on the stream every kernel of the step is launched on
     final_loss = float(loss.detach())
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_ddp:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t)
 
@@ -170,7 +175,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_ddp:
         dist.destroy_process_group()
 
 

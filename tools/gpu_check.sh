@@ -27,7 +27,9 @@ for step in "$@"; do
     smoke) run smoke 200 python -c "import __graft_entry__ as g; g.smoke()" ;;
     bench) run bench 400 python bench.py ;;
     bench32) run bench32 400 python bench.py --batch 32 --no-cpu-baseline ;;
+    bench64) run bench64 400 python bench.py --batch 64 --no-cpu-baseline --steps 15 ;;
     benchq) run benchq 300 python bench.py --no-cpu-baseline ;;
+    benchddp) BVC_FORCE_DDP=1 run benchddp 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --steps 20 --warmup 3 --no-cpu-baseline ;;
     benchov) BVC_DW_OVERLAP=1 run benchov 300 python bench.py --no-cpu-baseline ;;
     micro) run micro 400 python tools/microbench.py ;;
     probe) run probe 300 python tools/gemm_probe.py ;;

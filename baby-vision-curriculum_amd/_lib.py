@@ -66,6 +66,9 @@ SYMBOLS = {
     "bvc_op_layernorm_bwd_workspace": (c_int64, [c_int, c_int]),
     "bvc_op_colsum_bf16": (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
     "bvc_op_cast_bf16": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "bvc_op_row_normalize": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
+    "bvc_op_row_normalize_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "bvc_op_nce_finalize": (c_int, [c_void_p, c_int, c_float, c_int64, c_void_p, c_void_p, c_void_p]),
     "bvc_op_sgd_step": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_int, c_int, c_int,
                                 c_void_p, c_void_p, c_int, c_void_p]),
     "bvc_op_mask_index": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -21,7 +21,11 @@ enum GemmEpilogue {
     EPI_E2D = BVC_EPI_E2D,          // C f32[(m/rin)*rout + m%rin][n] = v + pos[rowtok[m]][n]
     EPI_LOSS = BVC_EPI_LOSS,        // d = v + bias - labels[m][n]; C bf16 = d; C2 f32 = v+bias (optional); partial[tile] = sum d^2
     EPI_DGELU = BVC_EPI_DGELU,      // C bf16 = v * gelu'(aux[m][n])
-    EPI_F32_BF16 = BVC_EPI_F32_BF16 // C f32 = v (+bias), C2 bf16 = same value
+    EPI_F32_BF16 = BVC_EPI_F32_BF16, // C f32 = v (+bias), C2 bf16 = same value
+    EPI_RELU = BVC_EPI_RELU,         // C bf16 = relu(v + bias)
+    EPI_DRELU = BVC_EPI_DRELU,       // C bf16 = v * (aux > 0)
+    EPI_NCE = BVC_EPI_NCE,           // SimCLR loss partials (no C): see gemm.hip
+    EPI_NCE_BWD = BVC_EPI_NCE_BWD    // C bf16 = d loss / d (cos/T)
 };
 
 // the public descriptor IS the internal problem record (include/bvc.h)

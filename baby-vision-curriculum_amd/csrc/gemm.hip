@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmGroup g) {
     // owns 8 consecutive columns and every global load / store of the epilogue is a full 128-B line per 8 lanes.
     const int epi = p.epi;
     const float alpha = p.alpha_dev ? p.alpha * p.alpha_dev[0] : p.alpha;
-    float sumsq = 0.f;
+    float sumsq = 0.f, possum = 0.f;
     const bool atomic = p.split_k > 1;
     constexpr int UNITS = WN / 4;                       // 16-B units per tile row
     AS3 char* wl = (AS3 char*)smem + wave * (WM * WN * 4);
@@ -317,6 +317,39 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmGroup g) {
                     store_f32(reinterpret_cast<float*>(p.C) + idx);
                     store_bf16(p.C2, idx, v);
                 } break;
+                case EPI_RELU: {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+                    store_bf16(p.C, idx, v);
+                } break;
+                case EPI_DRELU: {   // aux = the forward ReLU output: gradient passes where it was positive
+                    const uint4 a = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(p.aux) + (size_t)m * p.ldaux + n);
+                    const uint32_t w[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (!((w[e] & 0x7fffu) && !(w[e] & 0x8000u))) v[2 * e] = 0.f;
+                        if (!((w[e] & 0x7fff0000u) && !(w[e] & 0x80000000u))) v[2 * e + 1] = 0.f;
+                    }
+                    store_bf16(p.C, idx, v);
+                } break;
+                case EPI_NCE: {     // v = cos/T (alpha = 1/T): partial sums of exp(v - 1/T) over negatives and of v over positives
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int dj = n + e - m;
+                        if (dj == 1 || dj == -1) possum += v[e];
+                        else if (dj != 0) sumsq += __expf(v[e] - alpha);
+                    }
+                } break;
+                case EPI_NCE_BWD: { // labels = {lse, pos_coef}: C bf16 = d loss / d v
+                    const float lse = p.labels[0], pc = p.labels[1];
+                    float w[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int dj = n + e - m;
+                        w[e] = dj == 0 ? 0.f : (dj == 1 || dj == -1) ? pc : __expf(v[e] - lse);
+                    }
+                    store_bf16(p.C, idx, w);
+                } break;
                 default: break;
             }
         }
@@ -326,6 +359,17 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmGroup g) {
         for (int i = 0; i < TM; ++i) {
             const int m = m0 + wm * WM + 16 * i + lane;
             if (m < p.M) atomicAdd(p.rowsum + m, accb[i][0] * alpha);
+        }
+    }
+    if (epi == EPI_NCE) {    // two partials per tile: [2 tile] = sum over negatives, [2 tile + 1] = sum over positives
+        float* red = reinterpret_cast<float*>(smem);
+        const float w0 = wave_sum(sumsq), w1 = wave_sum(possum);
+        __syncthreads();
+        if (lane == 0) { red[wave] = w0; red[4 + wave] = w1; }
+        __syncthreads();
+        if (tid == 0) {
+            p.partial[2 * tile] = (red[0] + red[1]) + (red[2] + red[3]);
+            p.partial[2 * tile + 1] = (red[4] + red[5]) + (red[6] + red[7]);
         }
     }
     if (epi == EPI_LOSS) {   // uniform per workgroup: deterministic per-tile partial of sum (logit-label)^2

@@ -31,6 +31,9 @@ int launch_fill_masked(float* xfull, const float* mask_token, const float* pos, 
                        int nmask, int D, hipStream_t s);
 int launch_sgd_step(float* p, float* g, float* buf, size_t n, float lr, float momentum, float dampening, float wd, int nesterov,
                     int first, int maximize, const float* grad_scale, const float* found_inf, int write_grad, hipStream_t s);
+int launch_row_normalize(const float* f, bf16_t* fn, float* inv, int n, int p, float eps, hipStream_t s);
+int launch_row_normalize_bwd(const float* f, const float* inv, const float* dfn, float* df, int n, int p, hipStream_t s);
+int launch_nce_finalize(const float* partial, int ntiles, float inv_t, double npos, float* loss, float* stats, hipStream_t s);
 int launch_loss_finalize(const float* partial, int n, double count, const int* status, float* loss, hipStream_t s);
 
 }  // namespace bvc

@@ -329,6 +329,58 @@ __global__ __launch_bounds__(256) void loss_finalize_kernel(const float* __restr
     if (threadIdx.x == 0) *loss = (status && *status) ? __int_as_float(0x7fc00000) : (float)(red[0] / count);
 }
 
+// ============================================================================ SimCLR loss pieces
+// fn = f / max(||f||, eps) in bf16 (operand of the similarity GEMM), inv[i] = 1 / max(||f_i||, eps);
+// F.cosine_similarity semantics (pretraining/contrastive/pretrain_simclr.py:116).  One wave per row.
+__global__ __launch_bounds__(256) void row_normalize_kernel(const float* __restrict__ f, bf16_t* __restrict__ fn,
+                                                            float* __restrict__ inv, int n, int p, float eps) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const f32x4* fr = reinterpret_cast<const f32x4*>(f + (size_t)row * p);
+    float ss = 0.f;
+    for (int c = lane; c < p / 4; c += 64) { const f32x4 v = fr[c]; ss += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3]; }
+    const float r = 1.f / fmaxf(sqrtf(wave_sum(ss)), eps);
+    if (lane == 0) inv[row] = r;
+    uint2* o = reinterpret_cast<uint2*>(fn + (size_t)row * p);
+    for (int c = lane; c < p / 4; c += 64) { const f32x4 v = fr[c] * r; o[c] = uint2{pack2bf(v[0], v[1]), pack2bf(v[2], v[3])}; }
+}
+
+// df = inv * (dfn - fhat * (fhat . dfn)),  fhat = f * inv   (backward of the row normalisation)
+__global__ __launch_bounds__(256) void row_normalize_bwd_kernel(const float* __restrict__ f, const float* __restrict__ inv,
+                                                                const float* __restrict__ dfn, float* __restrict__ df, int n, int p) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const f32x4* fr = reinterpret_cast<const f32x4*>(f + (size_t)row * p);
+    const f32x4* gr = reinterpret_cast<const f32x4*>(dfn + (size_t)row * p);
+    const float r = inv[row];
+    float dot = 0.f;
+    for (int c = lane; c < p / 4; c += 64) { const f32x4 a = fr[c] * r, g = gr[c]; dot += a[0] * g[0] + a[1] * g[1] + a[2] * g[2] + a[3] * g[3]; }
+    dot = wave_sum(dot);
+    f32x4* o = reinterpret_cast<f32x4*>(df + (size_t)row * p);
+    for (int c = lane; c < p / 4; c += 64) { const f32x4 a = fr[c] * r; o[c] = (gr[c] - a * dot) * r; }
+}
+
+// loss = logsumexp(negatives) - mean(positives) from the per-tile partials of the EPI_NCE similarity GEMM
+// (partial[2t] = sum exp(s - 1/T) over negatives, partial[2t+1] = sum s over positives); stats = {lse, -1/npos}
+__global__ __launch_bounds__(256) void nce_finalize_kernel(const float* __restrict__ partial, int ntiles, float inv_t,
+                                                           double npos, float* __restrict__ loss, float* __restrict__ stats) {
+    __shared__ double red[2][256];
+    double a = 0.0, b = 0.0;
+    for (int i = threadIdx.x; i < ntiles; i += 256) { a += (double)partial[2 * i]; b += (double)partial[2 * i + 1]; }
+    red[0][threadIdx.x] = a; red[1][threadIdx.x] = b;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) { red[0][threadIdx.x] += red[0][threadIdx.x + o]; red[1][threadIdx.x] += red[1][threadIdx.x + o]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double lse = (double)inv_t + log(red[0][0]);
+        *loss = (float)(lse - red[1][0] / npos);
+        stats[0] = (float)lse;
+        stats[1] = (float)(-1.0 / npos);
+    }
+}
+
 // ============================================================================ fused SGD (momentum / Nesterov)
 // torch.optim.SGD semantics (pretrain_videomae.py:187-189) over a flat range, one pass:
 //   g = grad / grad_scale (+ wd * p);  buf = first ? g : m * buf + (1 - damp) * g;  d = nesterov ? g + m * buf : buf;
@@ -473,6 +525,26 @@ int launch_labels(const float* clip, const int* msk_idx, float* labels, int B, i
 int launch_fill_masked(float* xfull, const float* mask_token, const float* pos, const int* msk_idx, int B, int L, int nvis,
                        int nmask, int D, hipStream_t s) {
     hipLaunchKernelGGL(fill_masked_kernel, dim3(blocks_for((size_t)B * nmask * (D / 4))), dim3(256), 0, s, xfull, mask_token, pos, msk_idx, B, L, nvis, nmask, D);
+    BVC_CHECK_HIP(hipGetLastError());
+    return BVC_OK;
+}
+
+int launch_row_normalize(const float* f, bf16_t* fn, float* inv, int n, int p, float eps, hipStream_t s) {
+    BVC_REQUIRE(p % 4 == 0, "row_normalize: width must be a multiple of 4");
+    hipLaunchKernelGGL(row_normalize_kernel, dim3((n + 3) / 4), dim3(256), 0, s, f, fn, inv, n, p, eps);
+    BVC_CHECK_HIP(hipGetLastError());
+    return BVC_OK;
+}
+
+int launch_row_normalize_bwd(const float* f, const float* inv, const float* dfn, float* df, int n, int p, hipStream_t s) {
+    BVC_REQUIRE(p % 4 == 0, "row_normalize_bwd: width must be a multiple of 4");
+    hipLaunchKernelGGL(row_normalize_bwd_kernel, dim3((n + 3) / 4), dim3(256), 0, s, f, inv, dfn, df, n, p);
+    BVC_CHECK_HIP(hipGetLastError());
+    return BVC_OK;
+}
+
+int launch_nce_finalize(const float* partial, int ntiles, float inv_t, double npos, float* loss, float* stats, hipStream_t s) {
+    hipLaunchKernelGGL(nce_finalize_kernel, dim3(1), dim3(256), 0, s, partial, ntiles, inv_t, npos, loss, stats);
     BVC_CHECK_HIP(hipGetLastError());
     return BVC_OK;
 }

@@ -685,6 +685,18 @@ int bvc_op_sgd_step(float* params, float* grads, float* momentum_buf, int64_t n,
     return launch_sgd_step(params, grads, momentum_buf, (size_t)n, lr, momentum, dampening, weight_decay, nesterov, first_step,
                            maximize, grad_scale, found_inf, write_unscaled_grads, (hipStream_t)stream);
 }
+int bvc_op_row_normalize(const float* f, void* fn_bf16, float* inv_norm, int n, int p, float eps, void* stream) {
+    BVC_REQUIRE(f && fn_bf16 && inv_norm, "op_row_normalize: null argument");
+    return launch_row_normalize(f, (bf16_t*)fn_bf16, inv_norm, n, p, eps, (hipStream_t)stream);
+}
+int bvc_op_row_normalize_bwd(const float* f, const float* inv_norm, const float* dfn, float* df, int n, int p, void* stream) {
+    BVC_REQUIRE(f && inv_norm && dfn && df, "op_row_normalize_bwd: null argument");
+    return launch_row_normalize_bwd(f, inv_norm, dfn, df, n, p, (hipStream_t)stream);
+}
+int bvc_op_nce_finalize(const float* partial, int ntiles, float inv_temperature, int64_t npos, float* loss, float* stats, void* stream) {
+    BVC_REQUIRE(partial && loss && stats && ntiles > 0 && npos > 0, "op_nce_finalize: bad argument");
+    return launch_nce_finalize(partial, ntiles, inv_temperature, (double)npos, loss, stats, (hipStream_t)stream);
+}
 int bvc_op_cast_bf16(const float* in, void* out, int64_t n, void* stream) {
     BVC_REQUIRE(in && out && n >= 0, "op_cast_bf16: bad argument");
     return launch_cast_bf16(in, (bf16_t*)out, (size_t)n, (hipStream_t)stream);

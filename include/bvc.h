@@ -97,7 +97,8 @@ int bvc_videomae_tap(bvc_ctx* ctx, const char* name, float* dst_dev, int64_t cap
 enum { BVC_GEMM_NT = 0, BVC_GEMM_NN = 1, BVC_GEMM_TN = 2 };
 enum {
     BVC_EPI_F32 = 0, BVC_EPI_BF16 = 1, BVC_EPI_GELU = 2, BVC_EPI_RESID = 3, BVC_EPI_POS = 4, BVC_EPI_E2D = 5,
-    BVC_EPI_LOSS = 6, BVC_EPI_DGELU = 7, BVC_EPI_F32_BF16 = 8
+    BVC_EPI_LOSS = 6, BVC_EPI_DGELU = 7, BVC_EPI_F32_BF16 = 8, BVC_EPI_RELU = 9, BVC_EPI_DRELU = 10,
+    BVC_EPI_NCE = 11, BVC_EPI_NCE_BWD = 12
 };
 /* C[M,N] = epilogue(alpha * alpha_dev[0] * sum_k A(m,k) B(k,n)); bf16 operands, f32 accumulation.
  * Replaces the nn.Linear forward / backward GEMMs that ATen dispatches for HF:225-237,269-275,299-322. */
@@ -132,6 +133,13 @@ int bvc_op_layernorm_bwd(const void* dy_bf16, const float* x, int rin, int rout,
 int64_t bvc_op_layernorm_bwd_workspace(int M, int D);
 int bvc_op_colsum_bf16(const void* X, int M, int N, int ld, float alpha, const float* alpha_dev, float* out, void* stream);
 int bvc_op_cast_bf16(const float* in, void* out, int64_t n, void* stream);
+/* SimCLR loss pieces (info_nce_loss, pretraining/contrastive/pretrain_simclr.py:114-128, with its masks :284-292):
+ * row_normalize = the two norms of F.cosine_similarity; the (2B x 2B) similarity is a GEMM of the normalised rows with
+ * BVC_EPI_NCE (loss partials, nothing materialised) / BVC_EPI_NCE_BWD (bf16 d loss / d (cos/T)); nce_finalize folds
+ * the partials: loss = logsumexp over ALL negative entries - mean over the tridiagonal positives; stats = {lse, -1/npos}. */
+int bvc_op_row_normalize(const float* f, void* fn_bf16, float* inv_norm, int n, int p, float eps, void* stream);
+int bvc_op_row_normalize_bwd(const float* f, const float* inv_norm, const float* dfn, float* df, int n, int p, void* stream);
+int bvc_op_nce_finalize(const float* partial, int ntiles, float inv_temperature, int64_t npos, float* loss, float* stats, void* stream);
 /* One-pass torch.optim.SGD(momentum, nesterov) update over a flat f32 range, replacing the optimiser step at
  * pretrain_videomae.py:187-189,313.  grad_scale / found_inf are GradScaler's device scalars (may be NULL):
  * gradients are divided by *grad_scale, and nothing is touched when *found_inf != 0. */

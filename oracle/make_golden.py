@@ -139,10 +139,42 @@ def mask_fixture():
     print("[mask] reference TubeMaskingGenerator == oracle.tube_mask for", len(cases), "cases")
 
 
+def simclr_fixture():
+    """info_nce_loss / get_special_matrix of pretraining/contrastive/pretrain_simclr.py.  The module imports torchvision
+    (absent offline) at its top for the trunk only; empty in-memory stand-in modules let the import proceed so that the
+    two loss functions themselves - which use only torch/numpy - are the reference's own code."""
+    import types
+    from oracle import simclr_oracle as so
+    for name in ("torchvision", "torchvision.transforms", "torchvision.models", "torchvision.io", "torchvision.datasets",
+                 "torchvision.transforms.functional"):
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    sys.path.insert(0, os.path.join(REF, "pretraining", "contrastive"))
+    import pretrain_simclr as ref
+    cases = []
+    for B, p, seed in [(8, 128, 0), (32, 512, 1), (4, 64, 2)]:
+        feats = so.synthetic_features(2 * B, p, seed).requires_grad_(True)
+        masks = so.make_masks(B)
+        assert np.array_equal(ref.get_special_matrix(2 * B), so.get_special_matrix(2 * B))
+        loss = ref.info_nce_loss(0.1, masks, feats)
+        loss.backward()
+        mine = so.info_nce_loss(0.1, masks, feats.detach())
+        assert abs(float(mine) - float(loss)) < 1e-6
+        cases.append({"B": B, "p": p, "seed": seed, "temperature": 0.1, "n_pos": int(masks[0].sum()), "n_neg": int(masks[1].sum()),
+                      "loss": float(loss), "grad_l2": float(feats.grad.double().norm()),
+                      "grad_head": [float(x) for x in feats.grad.flatten()[:6]]})
+    with open(os.path.join(GOLD, "simclr_info_nce.json"), "w") as f:
+        json.dump({"source": "pretraining/contrastive/pretrain_simclr.py:86-91,114-128,284-292", "cases": cases}, f, indent=1)
+    print("[simclr] reference info_nce_loss == oracle for", len(cases), "cases; B=8:", cases[0]["n_pos"], "pos /", cases[0]["n_neg"], "neg")
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     torch.manual_seed(0)
     mask_fixture()
+    simclr_fixture()
+    if "--only-new" in sys.argv:
+        return
     one_case("tiny_s0", vo.TINY, batch=2, seed=0, mask_ratio=0.75)
     one_case("tiny_s1", vo.TINY, batch=3, seed=1, mask_ratio=0.75, wseed=1)
     one_case("base_b2_s0", vo.BASE, batch=2, seed=0, mask_ratio=0.9)

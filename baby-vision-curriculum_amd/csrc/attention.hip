@@ -40,17 +40,25 @@ namespace bvc {
 // swizzle of the 16-B chunk index of row r in a [rows][64] bf16 tile (128-B rows); serves both
 // ds_read_b128 row fragments (16 rows, one chunk) and tr reads (4 rows x 4 chunks).  Uses bits 1..3 of r
 // only, so adding a multiple of 16 rows to r is a plain byte offset.
-__device__ __forceinline__ int swz_dual(int r) { return (((r >> 1) & 1) << 2) | ((r >> 2) & 3); }
+// HD = 64: 128-B rows, 8 chunks.  HD = 32: 64-B rows (4 per 256-B bank row), 4 chunks: XOR with bits 2..3 of r.
+template <int HD>
+__device__ __forceinline__ int swz_dual(int r) {
+    if constexpr (HD == 64) return (((r >> 1) & 1) << 2) | ((r >> 2) & 3);
+    else return (r >> 2) & 3;
+}
 
-// stage rows [row0, row0+64) x 64 bf16 starting at element column `col0` of a [rows][ld] bf16 array
-// into an 8 KiB LDS image; 8 pieces of 1 KiB, two per wave
+// stage rows [row0, row0+64) x HD bf16 starting at element column `col0` of a [rows][ld] bf16 array
+// into a 64 x HD LDS image (8 KiB / 4 KiB); pieces of 1 KiB, two / one per wave
+template <int HD>
 __device__ __forceinline__ void stage64(__amdgpu_buffer_rsrc_t rs, int row0, int ld, int col0, char* lds,
                                         int wave, int lane) {
+    constexpr int CPR = HD / 8;                 // 16-B chunks per row
+    constexpr int RPP = 64 / CPR;               // rows per 1 KiB piece
 #pragma unroll
-    for (int jj = 0; jj < 2; ++jj) {
+    for (int jj = 0; jj < HD / 32; ++jj) {
         const int j = wave + 4 * jj;
-        const int r = 8 * j + (lane >> 3);
-        const int c = (lane & 7) ^ swz_dual(r);
+        const int r = RPP * j + lane / CPR;
+        const int c = (lane % CPR) ^ swz_dual<HD>(r);
         const uint32_t off = (uint32_t)(((size_t)(row0 + r) * ld + col0 + c * 8) * 2);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(lds + j * 1024), 16, off, 0, 0, 0);
     }
@@ -61,25 +69,28 @@ __device__ __forceinline__ void stage64(__amdgpu_buffer_rsrc_t rs, int row0, int
 //                 tile[r][16 st + 8 h + 0..7];   sub-tile s adds 4096 B
 //   tr[t][half] : transposed fragment, lane (i = l&31, h) -> tile[4 h + q + 8 half (+16 ks)][32 t + i];
 //                 k-step ks adds 2048 B, sub-tile s adds 4096 B
+template <int HD>
 struct FragAddr {
-    uint32_t rows[4];
-    uint32_t tr[2][2];
+    uint32_t rows[HD / 16];
+    uint32_t tr[HD / 32][2];
 };
 
-__device__ __forceinline__ FragAddr make_frag_addr(int lane) {
-    FragAddr a;
+template <int HD>
+__device__ __forceinline__ FragAddr<HD> make_frag_addr(int lane) {
+    FragAddr<HD> a;
+    constexpr int RB = HD * 2;   // bytes per tile row
     const int r = lane & 31, h = lane >> 5;
 #pragma unroll
-    for (int st = 0; st < 4; ++st) a.rows[st] = r * 128 + (((2 * st + h) ^ swz_dual(r)) << 4);
+    for (int st = 0; st < HD / 16; ++st) a.rows[st] = r * RB + (((2 * st + h) ^ swz_dual<HD>(r)) << 4);
     const int q = (lane >> 2) & 3, p = lane & 3;
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
+    for (int t = 0; t < HD / 32; ++t) {
         const int col = 32 * t + 16 * ((lane >> 4) & 1) + 4 * p;
         const int chunk = col >> 3, within = (col & 7) * 2;
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             const int r0 = 4 * h + q + 8 * half;
-            a.tr[t][half] = r0 * 128 + ((chunk ^ swz_dual(r0)) << 4) + within;
+            a.tr[t][half] = r0 * RB + ((chunk ^ swz_dual<HD>(r0)) << 4) + within;
         }
     }
     return a;
@@ -133,20 +144,20 @@ __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_ex
 constexpr float kDeferLog2 = 6.0f;   // rescale O only when the running max grows by more than 2^6
 
 // ============================================================================ forward
+template <int HD>
 struct FwdState {
-    f32x16 o0, o1;       // O^T rows d = 0..31 / 32..63, column = query
+    f32x16 o[HD / 32];   // O^T row blocks of 32 head dims, column = query
     float m_run, l_run;  // running max (log2 units), this lane half's share of the row sum
 };
 
 // one 32-key sub-tile; KOFF / VOFF = byte offsets of the K and V images of the stage (+ sub-tile)
-template <int KOFF, int VOFF>
-__device__ __forceinline__ void fwd_subtile(const AS3 char* lds, const FragAddr& fa, const bf16x8 (&qf)[4], FwdState& st,
+template <int HD, int KOFF, int VOFF>
+__device__ __forceinline__ void fwd_subtile(const AS3 char* lds, const FragAddr<HD>& fa, const bf16x8 (&qf)[HD / 16], FwdState<HD>& st,
                                             int key0, int N, int h, float scale_log2) {
+    constexpr int KS = 16 * HD * 2;
     f32x16 s = zero16();
-    s = MFMA32(lds_rows<KOFF>(lds, fa.rows[0]), qf[0], s);
-    s = MFMA32(lds_rows<KOFF>(lds, fa.rows[1]), qf[1], s);
-    s = MFMA32(lds_rows<KOFF>(lds, fa.rows[2]), qf[2], s);
-    s = MFMA32(lds_rows<KOFF>(lds, fa.rows[3]), qf[3], s);
+#pragma unroll
+    for (int stp = 0; stp < HD / 16; ++stp) s = MFMA32(lds_rows<KOFF>(lds, fa.rows[stp]), qf[stp], s);
     if (key0 + 32 > N) {   // ragged last tile only (workgroup-uniform branch)
         asm volatile("" ::: "memory");   // keep it a branch: if-converted, it costs 3 VALU per element on EVERY tile
 #pragma unroll
@@ -163,7 +174,9 @@ __device__ __forceinline__ void fwd_subtile(const AS3 char* lds, const FragAddr&
         st.m_run = m_new;
         st.l_run *= alpha;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { st.o0[r] *= alpha; st.o1[r] *= alpha; }
+        for (int t = 0; t < HD / 32; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st.o[t][r] *= alpha;
     }
     const float nm = -st.m_run;
     float rs = 0.f;
@@ -174,17 +187,19 @@ __device__ __forceinline__ void fwd_subtile(const AS3 char* lds, const FragAddr&
     }
     st.l_run += rs;
     const bf16x8 p0 = acc_to_frag(s, 0), p1 = acc_to_frag(s, 1);
-    st.o0 = MFMA32(lds_tr<VOFF>(lds, fa.tr[0][0], fa.tr[0][1]), p0, st.o0);
-    st.o1 = MFMA32(lds_tr<VOFF>(lds, fa.tr[1][0], fa.tr[1][1]), p0, st.o1);
-    st.o0 = MFMA32(lds_tr<VOFF + 2048>(lds, fa.tr[0][0], fa.tr[0][1]), p1, st.o0);
-    st.o1 = MFMA32(lds_tr<VOFF + 2048>(lds, fa.tr[1][0], fa.tr[1][1]), p1, st.o1);
+#pragma unroll
+    for (int t = 0; t < HD / 32; ++t) st.o[t] = MFMA32(lds_tr<VOFF>(lds, fa.tr[t][0], fa.tr[t][1]), p0, st.o[t]);
+#pragma unroll
+    for (int t = 0; t < HD / 32; ++t) st.o[t] = MFMA32(lds_tr<VOFF + KS>(lds, fa.tr[t][0], fa.tr[t][1]), p1, st.o[t]);
 }
 
 // grid (ceil(N/128), B*H); 256 threads; wave w owns queries q0 + 32 w .. + 31
+template <int HD>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx,
                                                           float* __restrict__ lse, int N, int H, int D,
                                                           uint32_t qkv_bytes, float scale_log2) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 stages x (K 8 KiB + V 8 KiB)
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 stages x (K image + V image)
+    constexpr int IMG = 64 * HD * 2, STG = 2 * IMG, SUB = 32 * HD * 2;
     const AS3 char* lds = (const AS3 char*)smem;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -193,74 +208,76 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
     const int qi = blockIdx.x * 128 + wave * 32 + (lane & 31);   // this lane's query
     const int h = lane >> 5;
     const __amdgpu_buffer_rsrc_t rs = make_rsrc(qkv, qkv_bytes);
-    const FragAddr fa = make_frag_addr(lane);
+    const FragAddr<HD> fa = make_frag_addr<HD>(lane);
 
-    bf16x8 qf[4];   // Q^T fragments (B operand of S^T = K Q^T): Q[qi][16 step + 8 h + 0..7]
+    bf16x8 qf[HD / 16];   // Q^T fragments (B operand of S^T = K Q^T): Q[qi][16 step + 8 h + 0..7]
     {
-        const bf16_t* qrow = qkv + (size_t)(b * N + min(qi, N - 1)) * ld + head * 64 + 8 * h;
+        const bf16_t* qrow = qkv + (size_t)(b * N + min(qi, N - 1)) * ld + head * HD + 8 * h;
 #pragma unroll
-        for (int st = 0; st < 4; ++st) qf[st] = load8(qrow + 16 * st);
+        for (int st = 0; st < HD / 16; ++st) qf[st] = load8(qrow + 16 * st);
     }
-    FwdState st;
-    st.o0 = zero16(); st.o1 = zero16();
+    FwdState<HD> st;
+#pragma unroll
+    for (int t = 0; t < HD / 32; ++t) st.o[t] = zero16();
     st.m_run = -INFINITY; st.l_run = 0.f;
 
     const int nkt = (N + 63) >> 6;
     const int krow0 = b * N;
     auto issue = [&](int kt, int stage) {
-        stage64(rs, krow0 + kt * 64, ld, D + head * 64, smem + stage * 16384, wave, lane);
-        stage64(rs, krow0 + kt * 64, ld, 2 * D + head * 64, smem + stage * 16384 + 8192, wave, lane);
+        stage64<HD>(rs, krow0 + kt * 64, ld, D + head * HD, smem + stage * STG, wave, lane);
+        stage64<HD>(rs, krow0 + kt * 64, ld, 2 * D + head * HD, smem + stage * STG + IMG, wave, lane);
     };
     issue(0, 0);
     for (int kt = 0; kt < nkt; kt += 2) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (kt + 1 < nkt) issue(kt + 1, 1);
-        fwd_subtile<0, 8192>(lds, fa, qf, st, kt * 64, N, h, scale_log2);
-        if (kt * 64 + 32 < N) fwd_subtile<4096, 8192 + 4096>(lds, fa, qf, st, kt * 64 + 32, N, h, scale_log2);
+        fwd_subtile<HD, 0, IMG>(lds, fa, qf, st, kt * 64, N, h, scale_log2);
+        if (kt * 64 + 32 < N) fwd_subtile<HD, SUB, IMG + SUB>(lds, fa, qf, st, kt * 64 + 32, N, h, scale_log2);
         if (kt + 1 >= nkt) break;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (kt + 2 < nkt) issue(kt + 2, 0);
-        fwd_subtile<16384, 16384 + 8192>(lds, fa, qf, st, kt * 64 + 64, N, h, scale_log2);
-        if (kt * 64 + 96 < N) fwd_subtile<16384 + 4096, 16384 + 8192 + 4096>(lds, fa, qf, st, kt * 64 + 96, N, h, scale_log2);
+        fwd_subtile<HD, STG, STG + IMG>(lds, fa, qf, st, kt * 64 + 64, N, h, scale_log2);
+        if (kt * 64 + 96 < N) fwd_subtile<HD, STG + SUB, STG + IMG + SUB>(lds, fa, qf, st, kt * 64 + 96, N, h, scale_log2);
     }
     const float l_tot = xhalf_sum(st.l_run);
     const float inv = 1.f / l_tot;
     if (qi < N) {
-        bf16_t* orow = ctx + (size_t)(b * N + qi) * D + head * 64;
+        bf16_t* orow = ctx + (size_t)(b * N + qi) * D + head * HD;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int d = 8 * g + 4 * h;
-            uint2 a = {pack2bf(st.o0[4 * g] * inv, st.o0[4 * g + 1] * inv), pack2bf(st.o0[4 * g + 2] * inv, st.o0[4 * g + 3] * inv)};
-            uint2 c = {pack2bf(st.o1[4 * g] * inv, st.o1[4 * g + 1] * inv), pack2bf(st.o1[4 * g + 2] * inv, st.o1[4 * g + 3] * inv)};
-            *reinterpret_cast<uint2*>(orow + d) = a;
-            *reinterpret_cast<uint2*>(orow + 32 + d) = c;
-        }
+        for (int t = 0; t < HD / 32; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int d = 32 * t + 8 * g + 4 * h;
+                uint2 a = {pack2bf(st.o[t][4 * g] * inv, st.o[t][4 * g + 1] * inv), pack2bf(st.o[t][4 * g + 2] * inv, st.o[t][4 * g + 3] * inv)};
+                *reinterpret_cast<uint2*>(orow + d) = a;
+            }
         if (h == 0) lse[(size_t)bh * N + qi] = st.m_run + log2f(l_tot);
     }
 }
 
 // ============================================================================ delta = rowsum(dO * O)
-// one thread per (row, head, 8-column chunk); 8 lanes per (row, head)
+// one thread per (row, head, 8-column chunk); HD/8 lanes per (row, head)
+template <int HD>
 __global__ void attn_delta_kernel(const bf16_t* __restrict__ dctx, const bf16_t* __restrict__ ctx,
                                   float* __restrict__ delta, int B, int N, int H, int D) {
+    constexpr int PCS = HD / 8;
     const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long long total = (long long)B * N * H * 8;
+    const long long total = (long long)B * N * H * PCS;
     float acc = 0.f;
-    long long item = gid >> 3;
-    const int piece = (int)(gid & 7);
+    long long item = gid / PCS;
+    const int piece = (int)(gid % PCS);
     if (gid < total) {
         const long long row = item / H;
         const int head = (int)(item % H);
-        const size_t off = (size_t)row * D + head * 64 + piece * 8;
+        const size_t off = (size_t)row * D + head * HD + piece * 8;
         const bf16x8 a = load8(dctx + off), o = load8(ctx + off);
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc += bf2f((bf16_t)a[j]) * bf2f((bf16_t)o[j]);
     }
-    acc += __shfl_xor(acc, 1, 64);
-    acc += __shfl_xor(acc, 2, 64);
-    acc += __shfl_xor(acc, 4, 64);
+#pragma unroll
+    for (int o = 1; o < PCS; o <<= 1) acc += __shfl_xor(acc, o, 64);
     if (gid < total && piece == 0) {
         const long long row = item / H;
         const int head = (int)(item % H);
@@ -270,13 +287,14 @@ __global__ void attn_delta_kernel(const bf16_t* __restrict__ dctx, const bf16_t*
 }
 
 // ============================================================================ dQ
-template <int KOFF, int VOFF>
-__device__ __forceinline__ void dq_subtile(const AS3 char* lds, const FragAddr& fa, const bf16x8 (&qf)[4], const bf16x8 (&dof)[4],
-                                           f32x16& dq0, f32x16& dq1, int key0, int N, int h, float scale_log2,
-                                           float nlse, float del_q) {
+template <int HD, int KOFF, int VOFF>
+__device__ __forceinline__ void dq_subtile(const AS3 char* lds, const FragAddr<HD>& fa, const bf16x8 (&qf)[HD / 16],
+                                           const bf16x8 (&dof)[HD / 16], f32x16 (&dq)[HD / 32], int key0, int N, int h,
+                                           float scale_log2, float nlse, float del_q) {
+    constexpr int KS = 16 * HD * 2;
     f32x16 s = zero16(), dp = zero16();
 #pragma unroll
-    for (int stp = 0; stp < 4; ++stp) {
+    for (int stp = 0; stp < HD / 16; ++stp) {
         s = MFMA32(lds_rows<KOFF>(lds, fa.rows[stp]), qf[stp], s);
         dp = MFMA32(lds_rows<VOFF>(lds, fa.rows[stp]), dof[stp], dp);
     }
@@ -290,18 +308,20 @@ __device__ __forceinline__ void dq_subtile(const AS3 char* lds, const FragAddr& 
             if (key0 + acc_row(r, h) >= N) s[r] = 0.f;
     }
     const bf16x8 d0 = acc_to_frag(s, 0), d1 = acc_to_frag(s, 1);
-    dq0 = MFMA32(lds_tr<KOFF>(lds, fa.tr[0][0], fa.tr[0][1]), d0, dq0);
-    dq1 = MFMA32(lds_tr<KOFF>(lds, fa.tr[1][0], fa.tr[1][1]), d0, dq1);
-    dq0 = MFMA32(lds_tr<KOFF + 2048>(lds, fa.tr[0][0], fa.tr[0][1]), d1, dq0);
-    dq1 = MFMA32(lds_tr<KOFF + 2048>(lds, fa.tr[1][0], fa.tr[1][1]), d1, dq1);
+#pragma unroll
+    for (int t = 0; t < HD / 32; ++t) dq[t] = MFMA32(lds_tr<KOFF>(lds, fa.tr[t][0], fa.tr[t][1]), d0, dq[t]);
+#pragma unroll
+    for (int t = 0; t < HD / 32; ++t) dq[t] = MFMA32(lds_tr<KOFF + KS>(lds, fa.tr[t][0], fa.tr[t][1]), d1, dq[t]);
 }
 
 // grid (ceil(N/128), B*H); wave w owns 32 queries; loops over key tiles (K and V staged)
+template <int HD>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dctx,
                                                              const float* __restrict__ lse, const float* __restrict__ delta,
                                                              bf16_t* __restrict__ dqkv, int N, int H, int D,
                                                              uint32_t qkv_bytes, float scale, float scale_log2) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int IMG = 64 * HD * 2, STG = 2 * IMG, SUB = 32 * HD * 2;
     const AS3 char* lds = (const AS3 char*)smem;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -311,70 +331,71 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
     const int qc = min(qi, N - 1);
     const int h = lane >> 5;
     const __amdgpu_buffer_rsrc_t rs = make_rsrc(qkv, qkv_bytes);
-    const FragAddr fa = make_frag_addr(lane);
+    const FragAddr<HD> fa = make_frag_addr<HD>(lane);
 
-    bf16x8 qf[4], dof[4];
+    bf16x8 qf[HD / 16], dof[HD / 16];
     {
-        const bf16_t* qrow = qkv + (size_t)(b * N + qc) * ld + head * 64 + 8 * h;
-        const bf16_t* drow = dctx + (size_t)(b * N + qc) * D + head * 64 + 8 * h;
+        const bf16_t* qrow = qkv + (size_t)(b * N + qc) * ld + head * HD + 8 * h;
+        const bf16_t* drow = dctx + (size_t)(b * N + qc) * D + head * HD + 8 * h;
 #pragma unroll
-        for (int st = 0; st < 4; ++st) { qf[st] = load8(qrow + 16 * st); dof[st] = load8(drow + 16 * st); }
+        for (int st = 0; st < HD / 16; ++st) { qf[st] = load8(qrow + 16 * st); dof[st] = load8(drow + 16 * st); }
     }
     const float nlse = -lse[(size_t)bh * N + qc];
     const float del_q = delta[(size_t)bh * N + qc];
-    f32x16 dq0 = zero16(), dq1 = zero16();
+    f32x16 dq[HD / 32];
+#pragma unroll
+    for (int t = 0; t < HD / 32; ++t) dq[t] = zero16();
 
     const int nkt = (N + 63) >> 6;
     const int krow0 = b * N;
     auto issue = [&](int kt, int stage) {
-        stage64(rs, krow0 + kt * 64, ld, D + head * 64, smem + stage * 16384, wave, lane);
-        stage64(rs, krow0 + kt * 64, ld, 2 * D + head * 64, smem + stage * 16384 + 8192, wave, lane);
+        stage64<HD>(rs, krow0 + kt * 64, ld, D + head * HD, smem + stage * STG, wave, lane);
+        stage64<HD>(rs, krow0 + kt * 64, ld, 2 * D + head * HD, smem + stage * STG + IMG, wave, lane);
     };
     issue(0, 0);
     for (int kt = 0; kt < nkt; kt += 2) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (kt + 1 < nkt) issue(kt + 1, 1);
-        dq_subtile<0, 8192>(lds, fa, qf, dof, dq0, dq1, kt * 64, N, h, scale_log2, nlse, del_q);
-        if (kt * 64 + 32 < N) dq_subtile<4096, 8192 + 4096>(lds, fa, qf, dof, dq0, dq1, kt * 64 + 32, N, h, scale_log2, nlse, del_q);
+        dq_subtile<HD, 0, IMG>(lds, fa, qf, dof, dq, kt * 64, N, h, scale_log2, nlse, del_q);
+        if (kt * 64 + 32 < N) dq_subtile<HD, SUB, IMG + SUB>(lds, fa, qf, dof, dq, kt * 64 + 32, N, h, scale_log2, nlse, del_q);
         if (kt + 1 >= nkt) break;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (kt + 2 < nkt) issue(kt + 2, 0);
-        dq_subtile<16384, 16384 + 8192>(lds, fa, qf, dof, dq0, dq1, kt * 64 + 64, N, h, scale_log2, nlse, del_q);
+        dq_subtile<HD, STG, STG + IMG>(lds, fa, qf, dof, dq, kt * 64 + 64, N, h, scale_log2, nlse, del_q);
         if (kt * 64 + 96 < N)
-            dq_subtile<16384 + 4096, 16384 + 8192 + 4096>(lds, fa, qf, dof, dq0, dq1, kt * 64 + 96, N, h, scale_log2, nlse, del_q);
+            dq_subtile<HD, STG + SUB, STG + IMG + SUB>(lds, fa, qf, dof, dq, kt * 64 + 96, N, h, scale_log2, nlse, del_q);
     }
     if (qi < N) {
-        bf16_t* orow = dqkv + (size_t)(b * N + qi) * ld + head * 64;
+        bf16_t* orow = dqkv + (size_t)(b * N + qi) * ld + head * HD;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int d = 8 * g + 4 * h;
-            uint2 a = {pack2bf(dq0[4 * g] * scale, dq0[4 * g + 1] * scale), pack2bf(dq0[4 * g + 2] * scale, dq0[4 * g + 3] * scale)};
-            uint2 c = {pack2bf(dq1[4 * g] * scale, dq1[4 * g + 1] * scale), pack2bf(dq1[4 * g + 2] * scale, dq1[4 * g + 3] * scale)};
-            *reinterpret_cast<uint2*>(orow + d) = a;
-            *reinterpret_cast<uint2*>(orow + 32 + d) = c;
-        }
+        for (int t = 0; t < HD / 32; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int d = 32 * t + 8 * g + 4 * h;
+                uint2 a = {pack2bf(dq[t][4 * g] * scale, dq[t][4 * g + 1] * scale), pack2bf(dq[t][4 * g + 2] * scale, dq[t][4 * g + 3] * scale)};
+                *reinterpret_cast<uint2*>(orow + d) = a;
+            }
     }
 }
 
 // ============================================================================ dK, dV
-// LDS stage = Q 8 KiB | dO 8 KiB | -lse 256 B | delta 256 B
-constexpr int kDkdvStage = 8192 * 2 + 512;
-
-template <int QOFF>
-__device__ __forceinline__ void dkdv_subtile(const AS3 char* lds, const FragAddr& fa, const bf16x8 (&kf)[4], const bf16x8 (&vf)[4],
-                                             f32x16& dk0, f32x16& dk1, f32x16& dv0, f32x16& dv1, int stat_off, int q0, int N,
-                                             int h, float scale_log2) {
-    constexpr int DOFF = QOFF + 8192;
+// LDS stage = Q image | dO image | -lse 256 B | delta 256 B
+template <int HD, int QOFF, int STAT>
+__device__ __forceinline__ void dkdv_subtile(const AS3 char* lds, const FragAddr<HD>& fa, const bf16x8 (&kf)[HD / 16],
+                                             const bf16x8 (&vf)[HD / 16], f32x16 (&dk)[HD / 32], f32x16 (&dv)[HD / 32], int q0,
+                                             int N, int h, float scale_log2) {
+    constexpr int IMG = 64 * HD * 2, KS = 16 * HD * 2;
+    constexpr int DOFF = QOFF + IMG;
     f32x16 s = zero16(), dp = zero16();
 #pragma unroll
-    for (int stp = 0; stp < 4; ++stp) {
+    for (int stp = 0; stp < HD / 16; ++stp) {
         s = MFMA32(lds_rows<QOFF>(lds, fa.rows[stp]), kf[stp], s);
         dp = MFMA32(lds_rows<DOFF>(lds, fa.rows[stp]), vf[stp], dp);
     }
     // rows of s/dp are queries: registers 4g..4g+3 <-> queries q0 + 8 g + 4 h + 0..3 (lse / delta broadcast from LDS)
-    const AS3 float* stl = reinterpret_cast<const AS3 float*>(lds + stat_off) + 4 * h;
+    const AS3 float* stl = reinterpret_cast<const AS3 float*>(lds + STAT) + 4 * h;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         const f32x4 ls = *reinterpret_cast<const AS3 f32x4*>(stl + 8 * g);
@@ -395,25 +416,28 @@ __device__ __forceinline__ void dkdv_subtile(const AS3 char* lds, const FragAddr
     }
     const bf16x8 p0 = acc_to_frag(s, 0), p1 = acc_to_frag(s, 1);
     const bf16x8 d0 = acc_to_frag(dp, 0), d1 = acc_to_frag(dp, 1);
-    dv0 = MFMA32(lds_tr<DOFF>(lds, fa.tr[0][0], fa.tr[0][1]), p0, dv0);
-    dv1 = MFMA32(lds_tr<DOFF>(lds, fa.tr[1][0], fa.tr[1][1]), p0, dv1);
-    dk0 = MFMA32(lds_tr<QOFF>(lds, fa.tr[0][0], fa.tr[0][1]), d0, dk0);
-    dk1 = MFMA32(lds_tr<QOFF>(lds, fa.tr[1][0], fa.tr[1][1]), d0, dk1);
-    dv0 = MFMA32(lds_tr<DOFF + 2048>(lds, fa.tr[0][0], fa.tr[0][1]), p1, dv0);
-    dv1 = MFMA32(lds_tr<DOFF + 2048>(lds, fa.tr[1][0], fa.tr[1][1]), p1, dv1);
-    dk0 = MFMA32(lds_tr<QOFF + 2048>(lds, fa.tr[0][0], fa.tr[0][1]), d1, dk0);
-    dk1 = MFMA32(lds_tr<QOFF + 2048>(lds, fa.tr[1][0], fa.tr[1][1]), d1, dk1);
+#pragma unroll
+    for (int t = 0; t < HD / 32; ++t) {
+        dv[t] = MFMA32(lds_tr<DOFF>(lds, fa.tr[t][0], fa.tr[t][1]), p0, dv[t]);
+        dk[t] = MFMA32(lds_tr<QOFF>(lds, fa.tr[t][0], fa.tr[t][1]), d0, dk[t]);
+    }
+#pragma unroll
+    for (int t = 0; t < HD / 32; ++t) {
+        dv[t] = MFMA32(lds_tr<DOFF + KS>(lds, fa.tr[t][0], fa.tr[t][1]), p1, dv[t]);
+        dk[t] = MFMA32(lds_tr<QOFF + KS>(lds, fa.tr[t][0], fa.tr[t][1]), d1, dk[t]);
+    }
 }
 
 // grid (ceil(N/128), B*H); wave w owns 32 keys; loops over query tiles (Q, dO, lse, delta staged)
+template <int HD>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dctx,
                                                                const float* __restrict__ lse, const float* __restrict__ delta,
                                                                bf16_t* __restrict__ dqkv, int N, int H, int D,
                                                                uint32_t qkv_bytes, uint32_t dctx_bytes, uint32_t stat_bytes,
                                                                float scale, float scale_log2) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int IMG = 64 * HD * 2, SUB = 32 * HD * 2, STG = 2 * IMG + 512;
     const AS3 char* lds = (const AS3 char*)smem;
-    constexpr int STG = kDkdvStage;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int bh = blockIdx.y, b = bh / H, head = bh % H;
@@ -425,91 +449,104 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const bf16_t* __r
     const __amdgpu_buffer_rsrc_t rd = make_rsrc(dctx, dctx_bytes);
     const __amdgpu_buffer_rsrc_t rl = make_rsrc(lse, stat_bytes);
     const __amdgpu_buffer_rsrc_t re = make_rsrc(delta, stat_bytes);
-    const FragAddr fa = make_frag_addr(lane);
+    const FragAddr<HD> fa = make_frag_addr<HD>(lane);
 
-    bf16x8 kf[4], vf[4];   // B operands of S = Q K^T and dP = dO V^T
+    bf16x8 kf[HD / 16], vf[HD / 16];   // B operands of S = Q K^T and dP = dO V^T
     {
-        const bf16_t* krow = qkv + (size_t)(b * N + kc) * ld + D + head * 64 + 8 * h;
+        const bf16_t* krow = qkv + (size_t)(b * N + kc) * ld + D + head * HD + 8 * h;
 #pragma unroll
-        for (int st = 0; st < 4; ++st) { kf[st] = load8(krow + 16 * st); vf[st] = load8(krow + D + 16 * st); }
+        for (int st = 0; st < HD / 16; ++st) { kf[st] = load8(krow + 16 * st); vf[st] = load8(krow + D + 16 * st); }
     }
-    f32x16 dk0 = zero16(), dk1 = zero16(), dv0 = zero16(), dv1 = zero16();
+    f32x16 dk[HD / 32], dv[HD / 32];
+#pragma unroll
+    for (int t = 0; t < HD / 32; ++t) { dk[t] = zero16(); dv[t] = zero16(); }
 
     const int nqt = (N + 63) >> 6;
     const int qrow0 = b * N;
     auto issue = [&](int qt, int stage) {
         char* dst = smem + stage * STG;
-        stage64(rq, qrow0 + qt * 64, ld, head * 64, dst, wave, lane);
-        stage64(rd, qrow0 + qt * 64, D, head * 64, dst + 8192, wave, lane);
+        stage64<HD>(rq, qrow0 + qt * 64, ld, head * HD, dst, wave, lane);
+        stage64<HD>(rd, qrow0 + qt * 64, D, head * HD, dst + IMG, wave, lane);
         if (wave == 0)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rl, LDS_PTR(dst + 16384), 4, (uint32_t)(((size_t)bh * N + qt * 64 + lane) * 4), 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rl, LDS_PTR(dst + 2 * IMG), 4, (uint32_t)(((size_t)bh * N + qt * 64 + lane) * 4), 0, 0, 0);
         if (wave == 1)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(re, LDS_PTR(dst + 16384 + 256), 4, (uint32_t)(((size_t)bh * N + qt * 64 + lane) * 4), 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(re, LDS_PTR(dst + 2 * IMG + 256), 4, (uint32_t)(((size_t)bh * N + qt * 64 + lane) * 4), 0, 0, 0);
     };
     issue(0, 0);
     for (int qt = 0; qt < nqt; qt += 2) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (qt + 1 < nqt) issue(qt + 1, 1);
-        dkdv_subtile<0>(lds, fa, kf, vf, dk0, dk1, dv0, dv1, 16384, qt * 64, N, h, scale_log2);
-        if (qt * 64 + 32 < N) dkdv_subtile<4096>(lds, fa, kf, vf, dk0, dk1, dv0, dv1, 16384 + 128, qt * 64 + 32, N, h, scale_log2);
+        dkdv_subtile<HD, 0, 2 * IMG>(lds, fa, kf, vf, dk, dv, qt * 64, N, h, scale_log2);
+        if (qt * 64 + 32 < N) dkdv_subtile<HD, SUB, 2 * IMG + 128>(lds, fa, kf, vf, dk, dv, qt * 64 + 32, N, h, scale_log2);
         if (qt + 1 >= nqt) break;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (qt + 2 < nqt) issue(qt + 2, 0);
-        dkdv_subtile<STG>(lds, fa, kf, vf, dk0, dk1, dv0, dv1, STG + 16384, qt * 64 + 64, N, h, scale_log2);
-        if (qt * 64 + 96 < N)
-            dkdv_subtile<STG + 4096>(lds, fa, kf, vf, dk0, dk1, dv0, dv1, STG + 16384 + 128, qt * 64 + 96, N, h, scale_log2);
+        dkdv_subtile<HD, STG, STG + 2 * IMG>(lds, fa, kf, vf, dk, dv, qt * 64 + 64, N, h, scale_log2);
+        if (qt * 64 + 96 < N) dkdv_subtile<HD, STG + SUB, STG + 2 * IMG + 128>(lds, fa, kf, vf, dk, dv, qt * 64 + 96, N, h, scale_log2);
     }
     if (ki < N) {
-        bf16_t* krow = dqkv + (size_t)(b * N + ki) * ld + D + head * 64;
+        bf16_t* krow = dqkv + (size_t)(b * N + ki) * ld + D + head * HD;
         bf16_t* vrow = krow + D;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int d = 8 * g + 4 * h;
-            uint2 a = {pack2bf(dk0[4 * g] * scale, dk0[4 * g + 1] * scale), pack2bf(dk0[4 * g + 2] * scale, dk0[4 * g + 3] * scale)};
-            uint2 c = {pack2bf(dk1[4 * g] * scale, dk1[4 * g + 1] * scale), pack2bf(dk1[4 * g + 2] * scale, dk1[4 * g + 3] * scale)};
-            *reinterpret_cast<uint2*>(krow + d) = a;
-            *reinterpret_cast<uint2*>(krow + 32 + d) = c;
-            uint2 e = {pack2bf(dv0[4 * g], dv0[4 * g + 1]), pack2bf(dv0[4 * g + 2], dv0[4 * g + 3])};
-            uint2 f = {pack2bf(dv1[4 * g], dv1[4 * g + 1]), pack2bf(dv1[4 * g + 2], dv1[4 * g + 3])};
-            *reinterpret_cast<uint2*>(vrow + d) = e;
-            *reinterpret_cast<uint2*>(vrow + 32 + d) = f;
-        }
+        for (int t = 0; t < HD / 32; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int d = 32 * t + 8 * g + 4 * h;
+                uint2 a = {pack2bf(dk[t][4 * g] * scale, dk[t][4 * g + 1] * scale), pack2bf(dk[t][4 * g + 2] * scale, dk[t][4 * g + 3] * scale)};
+                *reinterpret_cast<uint2*>(krow + d) = a;
+                uint2 e = {pack2bf(dv[t][4 * g], dv[t][4 * g + 1]), pack2bf(dv[t][4 * g + 2], dv[t][4 * g + 3])};
+                *reinterpret_cast<uint2*>(vrow + d) = e;
+            }
     }
 }
 
 // ============================================================================ host launchers
-int launch_attn_fwd(const bf16_t* qkv, bf16_t* ctx, float* lse, int B, int N, int H, hipStream_t stream) {
-    BVC_REQUIRE(B > 0 && N > 0 && H > 0, "attn_fwd: empty shape");
-    const int D = H * 64;
+template <int HD>
+static int fwd_hd(const bf16_t* qkv, bf16_t* ctx, float* lse, int B, int N, int H, hipStream_t stream) {
+    const int D = H * HD;
     const size_t bytes = (size_t)B * N * 3 * D * 2;
-    BVC_REQUIRE(bytes < 0xffffffffull, "attn_fwd: qkv larger than 4 GiB");
-    const float scale_log2 = 0.125f * 1.4426950408889634f;
+    const float scale_log2 = (1.0f / sqrtf((float)HD)) * 1.4426950408889634f;
     dim3 grid((N + 127) / 128, B * H);
-    hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), 32768, stream, qkv, ctx, lse, N, H, D, (uint32_t)bytes, scale_log2);
+    hipLaunchKernelGGL(attn_fwd_kernel<HD>, grid, dim3(256), 4 * 64 * HD * 2, stream, qkv, ctx, lse, N, H, D, (uint32_t)bytes, scale_log2);
     BVC_CHECK_HIP(hipGetLastError());
     return BVC_OK;
 }
 
-int launch_attn_bwd(const bf16_t* qkv, const bf16_t* ctx, const bf16_t* dctx, const float* lse, float* delta,
-                    bf16_t* dqkv, int B, int N, int H, hipStream_t stream) {
-    BVC_REQUIRE(B > 0 && N > 0 && H > 0, "attn_bwd: empty shape");
-    const int D = H * 64;
+template <int HD>
+static int bwd_hd(const bf16_t* qkv, const bf16_t* ctx, const bf16_t* dctx, const float* lse, float* delta, bf16_t* dqkv, int B,
+                  int N, int H, hipStream_t stream) {
+    const int D = H * HD;
     const size_t bytes = (size_t)B * N * 3 * D * 2;
-    BVC_REQUIRE(bytes < 0xffffffffull, "attn_bwd: qkv larger than 4 GiB");
-    const float scale = 0.125f, scale_log2 = 0.125f * 1.4426950408889634f;
+    const float scale = 1.0f / sqrtf((float)HD), scale_log2 = scale * 1.4426950408889634f;
     {
-        const long long total = (long long)B * N * H * 8;
-        hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, dctx, ctx, delta, B, N, H, D);
+        const long long total = (long long)B * N * H * (HD / 8);
+        hipLaunchKernelGGL(attn_delta_kernel<HD>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, dctx, ctx, delta, B, N, H, D);
     }
     dim3 grid((N + 127) / 128, B * H);
-    hipLaunchKernelGGL(attn_bwd_dkdv_kernel, grid, dim3(256), 2 * kDkdvStage, stream, qkv, dctx, lse, delta, dqkv, N, H, D,
+    hipLaunchKernelGGL(attn_bwd_dkdv_kernel<HD>, grid, dim3(256), 2 * (2 * 64 * HD * 2 + 512), stream, qkv, dctx, lse, delta, dqkv, N, H, D,
                        (uint32_t)bytes, (uint32_t)((size_t)B * N * D * 2), (uint32_t)((size_t)B * H * N * 4), scale, scale_log2);
-    hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 32768, stream, qkv, dctx, lse, delta, dqkv, N, H, D,
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<HD>, grid, dim3(256), 4 * 64 * HD * 2, stream, qkv, dctx, lse, delta, dqkv, N, H, D,
                        (uint32_t)bytes, scale, scale_log2);
     BVC_CHECK_HIP(hipGetLastError());
     return BVC_OK;
+}
+
+int launch_attn_fwd(const bf16_t* qkv, bf16_t* ctx, float* lse, int B, int N, int H, int head_dim, hipStream_t stream) {
+    BVC_REQUIRE(B > 0 && N > 0 && H > 0, "attn_fwd: empty shape");
+    BVC_REQUIRE(head_dim == 64 || head_dim == 32, "attn_fwd: head_dim %d unsupported (32 or 64)", head_dim);
+    BVC_REQUIRE((size_t)B * N * 3 * H * head_dim * 2 < 0xffffffffull, "attn_fwd: qkv larger than 4 GiB");
+    return head_dim == 64 ? fwd_hd<64>(qkv, ctx, lse, B, N, H, stream) : fwd_hd<32>(qkv, ctx, lse, B, N, H, stream);
+}
+
+int launch_attn_bwd(const bf16_t* qkv, const bf16_t* ctx, const bf16_t* dctx, const float* lse, float* delta,
+                    bf16_t* dqkv, int B, int N, int H, int head_dim, hipStream_t stream) {
+    BVC_REQUIRE(B > 0 && N > 0 && H > 0, "attn_bwd: empty shape");
+    BVC_REQUIRE(head_dim == 64 || head_dim == 32, "attn_bwd: head_dim %d unsupported (32 or 64)", head_dim);
+    BVC_REQUIRE((size_t)B * N * 3 * H * head_dim * 2 < 0xffffffffull, "attn_bwd: qkv larger than 4 GiB");
+    return head_dim == 64 ? bwd_hd<64>(qkv, ctx, dctx, lse, delta, dqkv, B, N, H, stream)
+                          : bwd_hd<32>(qkv, ctx, dctx, lse, delta, dqkv, B, N, H, stream);
 }
 
 }  // namespace bvc

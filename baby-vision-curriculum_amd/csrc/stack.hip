@@ -1,0 +1,257 @@
+// Shared pre-LN transformer stack: allocation, one-layer forward / backward schedules (host code).
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+
+#include "stack.h"
+
+namespace bvc {
+
+int64_t ParamTable::add(const std::string& name, std::initializer_list<int64_t> shp) {
+    ParamEntry e;
+    e.name = name;
+    e.offset = total;
+    e.numel = 1;
+    e.ndim = (int)shp.size();
+    int i = 0;
+    for (auto s : shp) { e.shape[i++] = s; e.numel *= s; }
+    for (; i < 5; ++i) e.shape[i] = 1;
+    entries.push_back(e);
+    total += e.numel;
+    return e.offset;
+}
+
+// hf_names: transformers' VideoMAELayer keys (separate query/key/value tensors, adjacent in memory);
+// otherwise the JEPA Block keys (norm1, attn.qkv, attn.proj, norm2, mlp.fc1, mlp.fc2)
+LayerOff add_layer_params(ParamTable& t, const std::string& p, int64_t d, int64_t inter, bool hf_names) {
+    LayerOff o;
+    if (hf_names) {
+        o.ln1w = t.add(p + "layernorm_before.weight", {d});
+        o.ln1b = t.add(p + "layernorm_before.bias", {d});
+        o.wqkv = t.add(p + "attention.attention.query.weight", {d, d});
+        t.add(p + "attention.attention.key.weight", {d, d});
+        t.add(p + "attention.attention.value.weight", {d, d});
+        o.bqkv = t.add(p + "attention.attention.query.bias", {d});
+        t.add(p + "attention.attention.key.bias", {d});
+        t.add(p + "attention.attention.value.bias", {d});
+        o.wo = t.add(p + "attention.output.dense.weight", {d, d});
+        o.bo = t.add(p + "attention.output.dense.bias", {d});
+        o.ln2w = t.add(p + "layernorm_after.weight", {d});
+        o.ln2b = t.add(p + "layernorm_after.bias", {d});
+        o.w1 = t.add(p + "intermediate.dense.weight", {inter, d});
+        o.b1 = t.add(p + "intermediate.dense.bias", {inter});
+        o.w2 = t.add(p + "output.dense.weight", {d, inter});
+        o.b2 = t.add(p + "output.dense.bias", {d});
+    } else {
+        o.ln1w = t.add(p + "norm1.weight", {d});
+        o.ln1b = t.add(p + "norm1.bias", {d});
+        o.wqkv = t.add(p + "attn.qkv.weight", {3 * d, d});
+        o.bqkv = t.add(p + "attn.qkv.bias", {3 * d});
+        o.wo = t.add(p + "attn.proj.weight", {d, d});
+        o.bo = t.add(p + "attn.proj.bias", {d});
+        o.ln2w = t.add(p + "norm2.weight", {d});
+        o.ln2b = t.add(p + "norm2.bias", {d});
+        o.w1 = t.add(p + "mlp.fc1.weight", {inter, d});
+        o.b1 = t.add(p + "mlp.fc1.bias", {inter});
+        o.w2 = t.add(p + "mlp.fc2.weight", {d, inter});
+        o.b2 = t.add(p + "mlp.fc2.bias", {d});
+    }
+    o.end = t.total;
+    return o;
+}
+
+int alloc_stack(Arena& a, Stack& s, int D, int I, int H, int nlayers, float eps, size_t M, size_t BHN) {
+    s.D = D; s.I = I; s.H = H; s.nlayers = nlayers; s.eps = eps;
+    s.act.resize(nlayers);
+    for (auto& l : s.act) {
+        TRY(a.alloc(&l.x_in, M * D));
+        TRY(a.alloc(&l.h, M * D));
+        TRY(a.alloc(&l.ln1o, M * D));
+        TRY(a.alloc(&l.qkv, M * 3 * D));
+        TRY(a.alloc(&l.ctx, M * D));
+        TRY(a.alloc(&l.lse, BHN));
+        TRY(a.alloc(&l.ln2o, M * D));
+        TRY(a.alloc(&l.pre, M * I));
+        TRY(a.alloc(&l.act, M * I));
+        TRY(a.alloc(&l.mean1, M));
+        TRY(a.alloc(&l.rstd1, M));
+        TRY(a.alloc(&l.mean2, M));
+        TRY(a.alloc(&l.rstd2, M));
+    }
+    TRY(a.alloc(&s.x_out, M * D));
+    return BVC_OK;
+}
+
+int alloc_work(Arena& a, Work& w, size_t MD, size_t MI, size_t delta_elems, size_t lnpart_elems) {
+    for (int i = 0; i < 3; ++i) TRY(a.alloc(&w.dyb[i], MD));
+    for (int i = 0; i < 2; ++i) {
+        TRY(a.alloc(&w.dhb[i], MD));
+        TRY(a.alloc(&w.dqkv[i], 3 * MD));
+        TRY(a.alloc(&w.dh[i], MI));
+    }
+    TRY(a.alloc(&w.dln, MD));
+    TRY(a.alloc(&w.dctx, MD));
+    TRY(a.alloc(&w.delta, delta_elems));
+    TRY(a.alloc(&w.ln_part, lnpart_elems));
+    // Measured on MI355X (B=16): running the grouped dW launch on a side stream next to the dX chain gains nothing
+    // (1398 vs 1419 clips/s) - each GEMM already holds all of a CU's LDS - so it is opt-in for experiments.
+    w.overlap = getenv("BVC_DW_OVERLAP") != nullptr;
+    BVC_CHECK_HIP(hipStreamCreateWithFlags(&w.side, hipStreamNonBlocking));
+    BVC_CHECK_HIP(hipEventCreateWithFlags(&w.ev_fork, hipEventDisableTiming));
+    BVC_CHECK_HIP(hipEventCreateWithFlags(&w.ev_join[0], hipEventDisableTiming));
+    BVC_CHECK_HIP(hipEventCreateWithFlags(&w.ev_join[1], hipEventDisableTiming));
+    return BVC_OK;
+}
+
+void free_work(Work& w) {
+    if (w.side) { (void)hipStreamSynchronize(w.side); (void)hipStreamDestroy(w.side); w.side = nullptr; }
+    if (w.ev_fork) { (void)hipEventDestroy(w.ev_fork); w.ev_fork = nullptr; }
+    for (int i = 0; i < 2; ++i) if (w.ev_join[i]) { (void)hipEventDestroy(w.ev_join[i]); w.ev_join[i] = nullptr; }
+}
+
+void begin_backward(Work& w) {
+    w.seq = 0;
+    w.join_pending[0] = w.join_pending[1] = false;
+}
+
+GemmProblem gemm(const bf16_t* A, size_t a_elems, int lda, const bf16_t* B, size_t b_elems, int ldb, int M, int N, int K,
+                 int epi, void* C, int ldc) {
+    GemmProblem p;
+    memset(&p, 0, sizeof(p));
+    p.A = A; p.B = B; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb;
+    p.a_bytes = (uint32_t)(a_elems * 2); p.b_bytes = (uint32_t)(b_elems * 2);
+    p.alpha = 1.f; p.epi = epi; p.split_k = 1; p.C = C; p.ldc = ldc;
+    return p;
+}
+
+// Tile and split-K choice for a group of weight-gradient products (contraction over all tokens).
+// Measured (profiles/r01_b_microbench.json): when the 128x128 tiles alone cover the chip (encoder layer: 432)
+// use them unsplit; otherwise 64x64 tiles with just enough K-splits for ~850 workgroups (decoder layer: 432 x 2).
+int plan_dw(GemmProblem* g, int n) {
+    int t128 = 0, t64 = 0;
+    for (int i = 0; i < n; ++i) {
+        t128 += ((g[i].M + 127) / 128) * ((g[i].N + 127) / 128);
+        t64 += ((g[i].M + 63) / 64) * ((g[i].N + 63) / 64);
+    }
+    if (t128 >= 400) return 0;
+    for (int i = 0; i < n; ++i) {
+        const int ksteps = (g[i].K + 63) / 64;
+        int s = (864 + t64 / 2) / t64;
+        s = std::min(s, std::max(1, ksteps / 16));
+        g[i].split_k = std::max(1, s);
+    }
+    return 2;
+}
+
+int layer_forward(Work& w, Stack& s, int li, const LayerOff& o, const float* x_in, float* x_out, int B, int N, hipStream_t st) {
+    LayerAct& a = s.act[li];
+    const int D = s.D, I = s.I, M = B * N;
+    const float* P = w.params;
+    const bf16_t* W = w.wbf;
+    const float eps = s.eps;
+    TRY(launch_ln_fwd(x_in, identity_rows(), P + o.ln1w, P + o.ln1b, a.ln1o, a.mean1, a.rstd1, M, D, eps, st));
+    {
+        GemmProblem p = gemm(a.ln1o, (size_t)M * D, D, W + o.wqkv, (size_t)3 * D * D, D, M, 3 * D, D, EPI_BF16, a.qkv, 3 * D);
+        p.bias = P + o.bqkv;
+        TRY(launch_gemm(&p, 1, GEMM_NT, -1, st));
+    }
+    TRY(launch_attn_fwd(a.qkv, a.ctx, a.lse, B, N, s.H, s.D / s.H, st));
+    {
+        GemmProblem p = gemm(a.ctx, (size_t)M * D, D, W + o.wo, (size_t)D * D, D, M, D, D, EPI_RESID, a.h, D);
+        p.bias = P + o.bo; p.resid = x_in;
+        TRY(launch_gemm(&p, 1, GEMM_NT, -1, st));
+    }
+    TRY(launch_ln_fwd(a.h, identity_rows(), P + o.ln2w, P + o.ln2b, a.ln2o, a.mean2, a.rstd2, M, D, eps, st));
+    {
+        GemmProblem p = gemm(a.ln2o, (size_t)M * D, D, W + o.w1, (size_t)I * D, D, M, I, D, EPI_GELU, a.pre, I);
+        p.bias = P + o.b1; p.C2 = a.act;
+        TRY(launch_gemm(&p, 1, GEMM_NT, -1, st));
+    }
+    {
+        GemmProblem p = gemm(a.act, (size_t)M * I, I, W + o.w2, (size_t)D * I, I, M, D, I, EPI_RESID, x_out, D);
+        p.bias = P + o.b2; p.resid = a.h;
+        TRY(launch_gemm(&p, 1, GEMM_NT, -1, st));
+    }
+    return BVC_OK;
+}
+
+// Fence a side-stream weight-gradient launch into the main stream and report its gradient range.
+int join_side(Work& c_, int parity, hipStream_t st, bvc_bucket_fn on_bucket, void* user) {
+    if (!c_.join_pending[parity]) return BVC_OK;
+    BVC_CHECK_HIP(hipStreamWaitEvent(st, c_.ev_join[parity], 0));
+    c_.join_pending[parity] = false;
+    if (on_bucket) on_bucket(c_.pend_lo[parity], c_.pend_hi[parity] - c_.pend_lo[parity], user);
+    return BVC_OK;
+}
+
+// dres (f32 [M][D]) holds d/d(layer output) on entry and d/d(layer input) on exit; dyb[seq % 3] is its bf16 copy.
+// The four weight gradients (+ bias gradients) of the layer are one grouped launch on the side stream, overlapping the
+// next layer's dX chain; its gradient range [o.ln1w, o.end) is reported when that launch has been fenced (two steps later).
+int layer_backward(Work& c_, Stack& s, int li, const LayerOff& o, const float* x_in, float* dres, float* G, int B, int N,
+                   hipStream_t st, bvc_bucket_fn on_bucket, void* user) {
+    LayerAct& a = s.act[li];
+    const int D = s.D, I = s.I, M = B * N;
+    const float* P = c_.params;
+    const bf16_t* W = c_.wbf;
+    const int q = c_.seq, par = q & 1;
+    bf16_t* dyb = c_.dyb[q % 3];
+    bf16_t* dyb_next = c_.dyb[(q + 1) % 3];
+    bf16_t *dh = c_.dh[par], *dhb = c_.dhb[par], *dqkv = c_.dqkv[par];
+    // the buffers of this parity were last read by the side launch of step q-2
+    TRY(join_side(c_, par, st, on_bucket, user));
+    // MLP
+    {
+        GemmProblem p = gemm(dyb, (size_t)M * D, D, W + o.w2, (size_t)D * I, I, M, I, D, EPI_DGELU, dh, I);
+        p.aux = a.pre; p.ldaux = I;
+        TRY(launch_gemm(&p, 1, GEMM_NN, -1, st));
+    }
+    {
+        GemmProblem p = gemm(dh, (size_t)M * I, I, W + o.w1, (size_t)I * D, D, M, D, I, EPI_BF16, c_.dln, D);
+        TRY(launch_gemm(&p, 1, GEMM_NN, -1, st));
+    }
+    TRY(launch_ln_bwd(c_.dln, a.h, identity_rows(), a.mean2, a.rstd2, P + o.ln2w, dres, 1, dhb, G + o.ln2w, G + o.ln2b, c_.ln_part, M, D, st));
+    // attention
+    {
+        GemmProblem p = gemm(dhb, (size_t)M * D, D, W + o.wo, (size_t)D * D, D, M, D, D, EPI_BF16, c_.dctx, D);
+        TRY(launch_gemm(&p, 1, GEMM_NN, -1, st));
+    }
+    TRY(launch_attn_bwd(a.qkv, a.ctx, c_.dctx, a.lse, c_.delta, dqkv, B, N, s.H, s.D / s.H, st));
+    {
+        GemmProblem p = gemm(dqkv, (size_t)M * 3 * D, 3 * D, W + o.wqkv, (size_t)3 * D * D, D, M, D, 3 * D, EPI_BF16, c_.dln, D);
+        TRY(launch_gemm(&p, 1, GEMM_NN, -1, st));
+    }
+    // the four weight gradients of the layer as one grouped launch:  dW = dY^T X,  db = column sums of dY
+    hipStream_t ws = st;
+    if (c_.overlap) {
+        BVC_CHECK_HIP(hipEventRecord(c_.ev_fork, st));
+        BVC_CHECK_HIP(hipStreamWaitEvent(c_.side, c_.ev_fork, 0));
+        ws = c_.side;
+    }
+    {
+        GemmProblem g[4];
+        g[0] = gemm(dyb, (size_t)M * D, D, a.act, (size_t)M * I, I, D, I, M, EPI_F32, G + o.w2, I);
+        g[1] = gemm(dh, (size_t)M * I, I, a.ln2o, (size_t)M * D, D, I, D, M, EPI_F32, G + o.w1, D);
+        g[2] = gemm(dhb, (size_t)M * D, D, a.ctx, (size_t)M * D, D, D, D, M, EPI_F32, G + o.wo, D);
+        g[3] = gemm(dqkv, (size_t)M * 3 * D, 3 * D, a.ln1o, (size_t)M * D, D, 3 * D, D, M, EPI_F32, G + o.wqkv, D);
+        g[0].rowsum = G + o.b2;     // bias gradients ride along as one extra MFMA column each
+        g[1].rowsum = G + o.b1;
+        g[2].rowsum = G + o.bo;
+        g[3].rowsum = G + o.bqkv;
+        const int tile = plan_dw(g, 4);
+        TRY(launch_gemm(g, 4, GEMM_TN, tile, ws));
+    }
+    TRY(launch_ln_bwd(c_.dln, x_in, identity_rows(), a.mean1, a.rstd1, P + o.ln1w, dres, 1, dyb_next, G + o.ln1w, G + o.ln1b, c_.ln_part, M, D, st));
+    if (c_.overlap) {
+        BVC_CHECK_HIP(hipEventRecord(c_.ev_join[par], c_.side));
+        c_.join_pending[par] = true;
+        c_.pend_lo[par] = o.ln1w;
+        c_.pend_hi[par] = o.end;
+    } else if (on_bucket) {
+        on_bucket(o.ln1w, o.end - o.ln1w, user);
+    }
+    c_.seq = q + 1;
+    return BVC_OK;
+}
+
+}  // namespace bvc

@@ -20,9 +20,7 @@
 #include <string>
 #include <vector>
 
-#include "attention.h"
-#include "gemm.h"
-#include "rowops.h"
+#include "stack.h"
 
 namespace bvc {
 static thread_local char g_err[1024] = "";
@@ -37,66 +35,13 @@ const char* last_error() { return g_err; }
 
 using namespace bvc;
 
-#define TRY(expr)                     \
-    do {                              \
-        int _rc = (expr);             \
-        if (_rc != BVC_OK) return _rc; \
-    } while (0)
-
 // ------------------------------------------------------------------ flat parameter layout
 namespace {
 
-struct LayerOff {
-    int64_t ln1w, ln1b, wqkv, bqkv, wo, bo, ln2w, ln2b, w1, b1, w2, b2, end;
-};
-
-struct ParamEntry {
-    std::string name;
-    int64_t offset, numel;
-    int ndim;
-    int64_t shape[5];
-};
-
-struct Layout {
-    std::vector<ParamEntry> entries;
-    int64_t total = 0;
+struct Layout : ParamTable {
     int64_t pe_w = 0, pe_b = 0, e2d_w = 0, mask_token = 0, norm_w = 0, norm_b = 0, head_w = 0, head_b = 0;
     std::vector<LayerOff> enc, dec;
 
-    int64_t add(const std::string& name, std::initializer_list<int64_t> shp) {
-        ParamEntry e;
-        e.name = name;
-        e.offset = total;
-        e.numel = 1;
-        e.ndim = (int)shp.size();
-        int i = 0;
-        for (auto s : shp) { e.shape[i++] = s; e.numel *= s; }
-        for (; i < 5; ++i) e.shape[i] = 1;
-        entries.push_back(e);
-        total += e.numel;
-        return e.offset;
-    }
-    LayerOff add_layer(const std::string& p, int64_t d, int64_t inter) {
-        LayerOff o;
-        o.ln1w = add(p + "layernorm_before.weight", {d});
-        o.ln1b = add(p + "layernorm_before.bias", {d});
-        o.wqkv = add(p + "attention.attention.query.weight", {d, d});   // q | k | v contiguous = one [3d][d] matrix
-        add(p + "attention.attention.key.weight", {d, d});
-        add(p + "attention.attention.value.weight", {d, d});
-        o.bqkv = add(p + "attention.attention.query.bias", {d});
-        add(p + "attention.attention.key.bias", {d});
-        add(p + "attention.attention.value.bias", {d});
-        o.wo = add(p + "attention.output.dense.weight", {d, d});
-        o.bo = add(p + "attention.output.dense.bias", {d});
-        o.ln2w = add(p + "layernorm_after.weight", {d});
-        o.ln2b = add(p + "layernorm_after.bias", {d});
-        o.w1 = add(p + "intermediate.dense.weight", {inter, d});
-        o.b1 = add(p + "intermediate.dense.bias", {inter});
-        o.w2 = add(p + "output.dense.weight", {d, inter});
-        o.b2 = add(p + "output.dense.bias", {d});
-        o.end = total;
-        return o;
-    }
 };
 
 int check_config(const bvc_videomae_config& c) {
@@ -120,11 +65,11 @@ Layout make_layout(const bvc_videomae_config& c) {
     L.pe_w = L.add(pe + "weight", {D, c.num_channels, c.tubelet_size, c.patch_size, c.patch_size});
     L.pe_b = L.add(pe + "bias", {D});
     for (int i = 0; i < c.num_hidden_layers; ++i)
-        L.enc.push_back(L.add_layer("videomae.encoder.layer." + std::to_string(i) + ".", D, c.intermediate_size));
+        L.enc.push_back(add_layer_params(L, "videomae.encoder.layer." + std::to_string(i) + ".", D, c.intermediate_size, true));
     L.e2d_w = L.add("encoder_to_decoder.weight", {Dd, D});
     L.mask_token = L.add("mask_token", {1, 1, Dd});
     for (int i = 0; i < c.decoder_num_hidden_layers; ++i)
-        L.dec.push_back(L.add_layer("decoder.decoder_layers." + std::to_string(i) + ".", Dd, c.decoder_intermediate_size));
+        L.dec.push_back(add_layer_params(L, "decoder.decoder_layers." + std::to_string(i) + ".", Dd, c.decoder_intermediate_size, true));
     L.norm_w = L.add("decoder.norm.weight", {Dd});
     L.norm_b = L.add("decoder.norm.bias", {Dd});
     L.head_w = L.add("decoder.head.weight", {P, Dd});
@@ -132,33 +77,14 @@ Layout make_layout(const bvc_videomae_config& c) {
     return L;
 }
 
-// saved activations of one transformer layer
-struct LayerAct {
-    float* x_in;      // f32 [M][D]  layer input (residual stream)
-    float* h;         // f32 [M][D]  after attention residual
-    bf16_t* ln1o;     // bf16 [M][D]
-    bf16_t* qkv;      // bf16 [M][3D]
-    bf16_t* ctx;      // bf16 [M][D]
-    float* lse;       // f32 [B*H][N]
-    bf16_t* ln2o;     // bf16 [M][D]
-    bf16_t* pre;      // bf16 [M][I]
-    bf16_t* act;      // bf16 [M][I]
-    float *mean1, *rstd1, *mean2, *rstd2;
-};
-
-struct Stack {   // encoder or decoder
-    int D, I, H, nlayers;
-    std::vector<LayerAct> act;
-    float* x_out;     // f32 [M][D] output of the last layer
-};
-
 }  // namespace
 
 struct bvc_ctx {
     bvc_videomae_config cfg;
     Layout lay;
     int max_batch, nmask, nvis, L, P, Kp;
-    std::vector<void*> allocs;
+    Arena arena;
+    Work w;
     // constants
     float *pos_enc, *pos_dec;
     // per-step state
@@ -176,54 +102,11 @@ struct bvc_ctx {
     bf16_t* diff;      // bf16 [B*nmask][P]  logits - labels
     float* partial;
     int npartial = 0;
-    // backward scratch (sized for the larger of encoder / decoder)
     float *dres_enc, *dres_dec;
-    // dY operands of the weight-gradient products are multi-buffered: the grouped dW launch of backward step s runs
-    // on the side stream while the main stream already works on step s+1 (buffers are reused at step s+2 / s+3)
-    bf16_t *dyb[3], *dhb[2], *dqkv[2], *dh[2];
-    bf16_t *dln, *dctx, *de2d;
-    float* delta;
-    hipStream_t side = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
-    bool overlap = true;
-    int seq = 0;                       // backward step counter of the current call
-    bool join_pending[2] = {false, false};
-    int64_t pend_lo[2], pend_hi[2];    // gradient range reported once the side stream's launch is fenced
-    float* ln_part;    // per-workgroup LayerNorm parameter-gradient partials
+    bf16_t* de2d;
 };
 
 namespace {
-
-template <typename T>
-int dev_alloc(bvc_ctx* c, T** p, size_t count) {
-    void* q = nullptr;
-    BVC_CHECK_HIP(hipMalloc(&q, count * sizeof(T) + 256));
-    c->allocs.push_back(q);
-    *p = reinterpret_cast<T*>(q);
-    return BVC_OK;
-}
-
-int alloc_stack(bvc_ctx* c, Stack& s, int D, int I, int H, int nlayers, size_t M, size_t BHN) {
-    s.D = D; s.I = I; s.H = H; s.nlayers = nlayers;
-    s.act.resize(nlayers);
-    for (auto& a : s.act) {
-        TRY(dev_alloc(c, &a.x_in, M * D));
-        TRY(dev_alloc(c, &a.h, M * D));
-        TRY(dev_alloc(c, &a.ln1o, M * D));
-        TRY(dev_alloc(c, &a.qkv, M * 3 * D));
-        TRY(dev_alloc(c, &a.ctx, M * D));
-        TRY(dev_alloc(c, &a.lse, BHN));
-        TRY(dev_alloc(c, &a.ln2o, M * D));
-        TRY(dev_alloc(c, &a.pre, M * I));
-        TRY(dev_alloc(c, &a.act, M * I));
-        TRY(dev_alloc(c, &a.mean1, M));
-        TRY(dev_alloc(c, &a.rstd1, M));
-        TRY(dev_alloc(c, &a.mean2, M));
-        TRY(dev_alloc(c, &a.rstd2, M));
-    }
-    TRY(dev_alloc(c, &s.x_out, M * D));
-    return BVC_OK;
-}
 
 void sinusoid(std::vector<float>& out, int n, int d) {   // HF:80-91, float64 then cast
     out.resize((size_t)n * d);
@@ -232,146 +115,6 @@ void sinusoid(std::vector<float>& out, int n, int d) {   // HF:80-91, float64 th
             const double ang = (double)p / pow(10000.0, 2.0 * (j / 2) / (double)d);
             out[(size_t)p * d + j] = (float)((j & 1) ? cos(ang) : sin(ang));
         }
-}
-
-GemmProblem gemm(const bf16_t* A, size_t a_elems, int lda, const bf16_t* B, size_t b_elems, int ldb, int M, int N, int K,
-                 int epi, void* C, int ldc) {
-    GemmProblem p;
-    memset(&p, 0, sizeof(p));
-    p.A = A; p.B = B; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb;
-    p.a_bytes = (uint32_t)(a_elems * 2); p.b_bytes = (uint32_t)(b_elems * 2);
-    p.alpha = 1.f; p.epi = epi; p.split_k = 1; p.C = C; p.ldc = ldc;
-    return p;
-}
-
-// Tile and split-K choice for a group of weight-gradient products (contraction over all tokens).
-// Measured (profiles/r01_b_microbench.json): when the 128x128 tiles alone cover the chip (encoder layer: 432)
-// use them unsplit; otherwise 64x64 tiles with just enough K-splits for ~850 workgroups (decoder layer: 432 x 2).
-int plan_dw(GemmProblem* g, int n) {
-    int t128 = 0, t64 = 0;
-    for (int i = 0; i < n; ++i) {
-        t128 += ((g[i].M + 127) / 128) * ((g[i].N + 127) / 128);
-        t64 += ((g[i].M + 63) / 64) * ((g[i].N + 63) / 64);
-    }
-    if (t128 >= 400) return 0;
-    for (int i = 0; i < n; ++i) {
-        const int ksteps = (g[i].K + 63) / 64;
-        int s = (864 + t64 / 2) / t64;
-        s = std::min(s, std::max(1, ksteps / 16));
-        g[i].split_k = std::max(1, s);
-    }
-    return 2;
-}
-
-int layer_forward(bvc_ctx* c, Stack& s, int li, const LayerOff& o, float* x_in_external, float* x_out, int B, int N, hipStream_t st) {
-    LayerAct& a = s.act[li];
-    const int D = s.D, I = s.I, M = B * N;
-    const float* P = c->params;
-    const bf16_t* W = c->wbf;
-    const float* x_in = x_in_external;
-    const float eps = c->cfg.layer_norm_eps;
-    TRY(launch_ln_fwd(x_in, identity_rows(), P + o.ln1w, P + o.ln1b, a.ln1o, a.mean1, a.rstd1, M, D, eps, st));
-    {
-        GemmProblem p = gemm(a.ln1o, (size_t)M * D, D, W + o.wqkv, (size_t)3 * D * D, D, M, 3 * D, D, EPI_BF16, a.qkv, 3 * D);
-        p.bias = P + o.bqkv;
-        TRY(launch_gemm(&p, 1, GEMM_NT, -1, st));
-    }
-    TRY(launch_attn_fwd(a.qkv, a.ctx, a.lse, B, N, s.H, st));
-    {
-        GemmProblem p = gemm(a.ctx, (size_t)M * D, D, W + o.wo, (size_t)D * D, D, M, D, D, EPI_RESID, a.h, D);
-        p.bias = P + o.bo; p.resid = x_in;
-        TRY(launch_gemm(&p, 1, GEMM_NT, -1, st));
-    }
-    TRY(launch_ln_fwd(a.h, identity_rows(), P + o.ln2w, P + o.ln2b, a.ln2o, a.mean2, a.rstd2, M, D, eps, st));
-    {
-        GemmProblem p = gemm(a.ln2o, (size_t)M * D, D, W + o.w1, (size_t)I * D, D, M, I, D, EPI_GELU, a.pre, I);
-        p.bias = P + o.b1; p.C2 = a.act;
-        TRY(launch_gemm(&p, 1, GEMM_NT, -1, st));
-    }
-    {
-        GemmProblem p = gemm(a.act, (size_t)M * I, I, W + o.w2, (size_t)D * I, I, M, D, I, EPI_RESID, x_out, D);
-        p.bias = P + o.b2; p.resid = a.h;
-        TRY(launch_gemm(&p, 1, GEMM_NT, -1, st));
-    }
-    return BVC_OK;
-}
-
-// Fence a side-stream weight-gradient launch into the main stream and report its gradient range.
-int join_side(bvc_ctx* c, int parity, hipStream_t st, bvc_bucket_fn on_bucket, void* user) {
-    if (!c->join_pending[parity]) return BVC_OK;
-    BVC_CHECK_HIP(hipStreamWaitEvent(st, c->ev_join[parity], 0));
-    c->join_pending[parity] = false;
-    if (on_bucket) on_bucket(c->pend_lo[parity], c->pend_hi[parity] - c->pend_lo[parity], user);
-    return BVC_OK;
-}
-
-// dres (f32 [M][D]) holds d/d(layer output) on entry and d/d(layer input) on exit; dyb[seq % 3] is its bf16 copy.
-// The four weight gradients (+ bias gradients) of the layer are one grouped launch on the side stream, overlapping the
-// next layer's dX chain; its gradient range [o.ln1w, o.end) is reported when that launch has been fenced (two steps later).
-int layer_backward(bvc_ctx* c, Stack& s, int li, const LayerOff& o, const float* x_in, float* dres, float* G, int B, int N,
-                   hipStream_t st, bvc_bucket_fn on_bucket, void* user) {
-    LayerAct& a = s.act[li];
-    const int D = s.D, I = s.I, M = B * N;
-    const float* P = c->params;
-    const bf16_t* W = c->wbf;
-    const int q = c->seq, par = q & 1;
-    bf16_t* dyb = c->dyb[q % 3];
-    bf16_t* dyb_next = c->dyb[(q + 1) % 3];
-    bf16_t *dh = c->dh[par], *dhb = c->dhb[par], *dqkv = c->dqkv[par];
-    // the buffers of this parity were last read by the side launch of step q-2
-    TRY(join_side(c, par, st, on_bucket, user));
-    // MLP
-    {
-        GemmProblem p = gemm(dyb, (size_t)M * D, D, W + o.w2, (size_t)D * I, I, M, I, D, EPI_DGELU, dh, I);
-        p.aux = a.pre; p.ldaux = I;
-        TRY(launch_gemm(&p, 1, GEMM_NN, -1, st));
-    }
-    {
-        GemmProblem p = gemm(dh, (size_t)M * I, I, W + o.w1, (size_t)I * D, D, M, D, I, EPI_BF16, c->dln, D);
-        TRY(launch_gemm(&p, 1, GEMM_NN, -1, st));
-    }
-    TRY(launch_ln_bwd(c->dln, a.h, identity_rows(), a.mean2, a.rstd2, P + o.ln2w, dres, 1, dhb, G + o.ln2w, G + o.ln2b, c->ln_part, M, D, st));
-    // attention
-    {
-        GemmProblem p = gemm(dhb, (size_t)M * D, D, W + o.wo, (size_t)D * D, D, M, D, D, EPI_BF16, c->dctx, D);
-        TRY(launch_gemm(&p, 1, GEMM_NN, -1, st));
-    }
-    TRY(launch_attn_bwd(a.qkv, a.ctx, c->dctx, a.lse, c->delta, dqkv, B, N, s.H, st));
-    {
-        GemmProblem p = gemm(dqkv, (size_t)M * 3 * D, 3 * D, W + o.wqkv, (size_t)3 * D * D, D, M, D, 3 * D, EPI_BF16, c->dln, D);
-        TRY(launch_gemm(&p, 1, GEMM_NN, -1, st));
-    }
-    // the four weight gradients of the layer as one grouped launch:  dW = dY^T X,  db = column sums of dY
-    hipStream_t ws = st;
-    if (c->overlap) {
-        BVC_CHECK_HIP(hipEventRecord(c->ev_fork, st));
-        BVC_CHECK_HIP(hipStreamWaitEvent(c->side, c->ev_fork, 0));
-        ws = c->side;
-    }
-    {
-        GemmProblem g[4];
-        g[0] = gemm(dyb, (size_t)M * D, D, a.act, (size_t)M * I, I, D, I, M, EPI_F32, G + o.w2, I);
-        g[1] = gemm(dh, (size_t)M * I, I, a.ln2o, (size_t)M * D, D, I, D, M, EPI_F32, G + o.w1, D);
-        g[2] = gemm(dhb, (size_t)M * D, D, a.ctx, (size_t)M * D, D, D, D, M, EPI_F32, G + o.wo, D);
-        g[3] = gemm(dqkv, (size_t)M * 3 * D, 3 * D, a.ln1o, (size_t)M * D, D, 3 * D, D, M, EPI_F32, G + o.wqkv, D);
-        g[0].rowsum = G + o.b2;     // bias gradients ride along as one extra MFMA column each
-        g[1].rowsum = G + o.b1;
-        g[2].rowsum = G + o.bo;
-        g[3].rowsum = G + o.bqkv;
-        const int tile = plan_dw(g, 4);
-        TRY(launch_gemm(g, 4, GEMM_TN, tile, ws));
-    }
-    TRY(launch_ln_bwd(c->dln, x_in, identity_rows(), a.mean1, a.rstd1, P + o.ln1w, dres, 1, dyb_next, G + o.ln1w, G + o.ln1b, c->ln_part, M, D, st));
-    if (c->overlap) {
-        BVC_CHECK_HIP(hipEventRecord(c->ev_join[par], c->side));
-        c->join_pending[par] = true;
-        c->pend_lo[par] = o.ln1w;
-        c->pend_hi[par] = o.end;
-    } else if (on_bucket) {
-        on_bucket(o.ln1w, o.end - o.ln1w, user);
-    }
-    c->seq = q + 1;
-    return BVC_OK;
 }
 
 }  // namespace
@@ -407,10 +150,8 @@ int bvc_videomae_param_info(const bvc_videomae_config* cfg, int index, char* nam
 
 void bvc_videomae_destroy(bvc_ctx* c) {
     if (!c) return;
-    if (c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamDestroy(c->side); }
-    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
-    for (int i = 0; i < 2; ++i) if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
-    for (void* p : c->allocs) (void)hipFree(p);
+    free_work(c->w);
+    c->arena.release();
     delete c;
 }
 
@@ -439,47 +180,29 @@ int bvc_videomae_create(const bvc_videomae_config* cfg, int max_batch, int num_m
     int rc = BVC_OK;
     auto fail = [&](int r) { bvc_videomae_destroy(c); return r; };
 #define A(expr) if ((rc = (expr)) != BVC_OK) return fail(rc)
-    A(dev_alloc(c, &c->pos_enc, (size_t)c->L * D));
-    A(dev_alloc(c, &c->pos_dec, (size_t)c->L * Dd));
-    A(dev_alloc(c, &c->wbf, (size_t)c->lay.total));
-    A(dev_alloc(c, &c->vis_idx, Mv));
-    A(dev_alloc(c, &c->msk_idx, Mm));
-    A(dev_alloc(c, &c->status, 4));
-    A(dev_alloc(c, &c->Ape, Mv * c->Kp));
-    A(alloc_stack(c, c->enc, D, I, H, cfg->num_hidden_layers, Mv, B * H * c->nvis));
-    A(alloc_stack(c, c->dec, Dd, Id, Hd, cfg->decoder_num_hidden_layers, Md, B * Hd * c->L));
-    A(dev_alloc(c, &c->xe_bf, Mv * D));
-    A(dev_alloc(c, &c->meanf, Mm));
-    A(dev_alloc(c, &c->rstdf, Mm));
-    A(dev_alloc(c, &c->lnf, Mm * Dd));
-    A(dev_alloc(c, &c->labels, Mm * c->P));
-    A(dev_alloc(c, &c->diff, Mm * c->P));
-    A(dev_alloc(c, &c->partial, (Mm / 64 + 2) * (c->P / 64 + 2)));
-    A(dev_alloc(c, &c->dres_enc, Mv * D));
-    A(dev_alloc(c, &c->dres_dec, Md * Dd));
+    A(c->arena.alloc(&c->pos_enc, (size_t)c->L * D));
+    A(c->arena.alloc(&c->pos_dec, (size_t)c->L * Dd));
+    A(c->arena.alloc(&c->wbf, (size_t)c->lay.total));
+    A(c->arena.alloc(&c->vis_idx, Mv));
+    A(c->arena.alloc(&c->msk_idx, Mm));
+    A(c->arena.alloc(&c->status, 4));
+    A(c->arena.alloc(&c->Ape, Mv * c->Kp));
+    A(alloc_stack(c->arena, c->enc, D, I, H, cfg->num_hidden_layers, cfg->layer_norm_eps, Mv, B * H * c->nvis));
+    A(alloc_stack(c->arena, c->dec, Dd, Id, Hd, cfg->decoder_num_hidden_layers, cfg->layer_norm_eps, Md, B * Hd * c->L));
+    A(c->arena.alloc(&c->xe_bf, Mv * D));
+    A(c->arena.alloc(&c->meanf, Mm));
+    A(c->arena.alloc(&c->rstdf, Mm));
+    A(c->arena.alloc(&c->lnf, Mm * Dd));
+    A(c->arena.alloc(&c->labels, Mm * c->P));
+    A(c->arena.alloc(&c->diff, Mm * c->P));
+    A(c->arena.alloc(&c->partial, (Mm / 64 + 2) * (c->P / 64 + 2)));
+    A(c->arena.alloc(&c->dres_enc, Mv * D));
+    A(c->arena.alloc(&c->dres_dec, Md * Dd));
     const size_t MD = std::max(Mv * D, Md * Dd), MI = std::max(Mv * I, Md * Id);
-    for (int i = 0; i < 3; ++i) A(dev_alloc(c, &c->dyb[i], MD));
-    for (int i = 0; i < 2; ++i) {
-        A(dev_alloc(c, &c->dhb[i], MD));
-        A(dev_alloc(c, &c->dqkv[i], 3 * MD));
-        A(dev_alloc(c, &c->dh[i], MI));
-    }
-    A(dev_alloc(c, &c->dln, MD));
-    A(dev_alloc(c, &c->dctx, MD));
-    A(dev_alloc(c, &c->de2d, Mv * Dd));
-    A(dev_alloc(c, &c->delta, std::max(B * H * c->nvis, B * Hd * c->L)));
-    A(dev_alloc(c, &c->ln_part, std::max(ln_bwd_workspace_floats_upto((int)Mv, D), ln_bwd_workspace_floats_upto((int)Md, Dd))));
+    A(c->arena.alloc(&c->de2d, Mv * Dd));
+    A(alloc_work(c->arena, c->w, MD, MI, std::max(B * H * c->nvis, B * Hd * c->L),
+                 std::max(ln_bwd_workspace_floats_upto((int)Mv, D), ln_bwd_workspace_floats_upto((int)Md, Dd))));
 #undef A
-    // Measured on MI355X (B=16): running the grouped dW launch on a side stream next to the dX chain gains nothing
-    // (1398 vs 1419 clips/s) - each GEMM already holds all of a CU's LDS - so it is opt-in for experiments.
-    c->overlap = getenv("BVC_DW_OVERLAP") != nullptr;
-    if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_join[0], hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_join[1], hipEventDisableTiming) != hipSuccess) {
-        set_error("create: side stream / events");
-        return fail(BVC_ERR_HIP);
-    }
     std::vector<float> tab;
     sinusoid(tab, c->L, D);
     if (hipMemcpy(c->pos_enc, tab.data(), tab.size() * 4, hipMemcpyHostToDevice) != hipSuccess) { set_error("create: pos upload failed"); return fail(BVC_ERR_HIP); }
@@ -502,6 +225,8 @@ int bvc_videomae_forward(bvc_ctx* c, const float* pixels, const uint8_t* mask, i
     c->have_forward = false;
     c->batch = B;
     c->params = params;
+    c->w.params = params;
+    c->w.wbf = c->wbf;
     const PatchGeom pg{cf.num_frames, cf.num_channels, cf.image_size, cf.image_size, cf.tubelet_size, cf.patch_size};
 
     TRY(launch_cast_bf16(params, c->wbf, (size_t)L.total, st));
@@ -516,7 +241,7 @@ int bvc_videomae_forward(bvc_ctx* c, const float* pixels, const uint8_t* mask, i
     }
     for (int i = 0; i < c->enc.nlayers; ++i) {
         float* xo = i + 1 < c->enc.nlayers ? c->enc.act[i + 1].x_in : c->enc.x_out;
-        TRY(layer_forward(c, c->enc, i, L.enc[i], c->enc.act[i].x_in, xo, B, nvis, st));
+        TRY(layer_forward(c->w, c->enc, i, L.enc[i], c->enc.act[i].x_in, xo, B, nvis, st));
     }
     // encoder -> decoder glue (HF:566-582)
     TRY(launch_gather_rows_bf16(c->enc.x_out, identity_rows(), c->xe_bf, Mv, D, st));
@@ -528,7 +253,7 @@ int bvc_videomae_forward(bvc_ctx* c, const float* pixels, const uint8_t* mask, i
     TRY(launch_fill_masked(c->dec.act[0].x_in, params + L.mask_token, c->pos_dec, c->msk_idx, B, Lq, nvis, nmask, Dd, st));
     for (int i = 0; i < c->dec.nlayers; ++i) {
         float* xo = i + 1 < c->dec.nlayers ? c->dec.act[i + 1].x_in : c->dec.x_out;
-        TRY(layer_forward(c, c->dec, i, L.dec[i], c->dec.act[i].x_in, xo, B, Lq, st));
+        TRY(layer_forward(c->w, c->dec, i, L.dec[i], c->dec.act[i].x_in, xo, B, Lq, st));
     }
     // last nmask tokens -> LayerNorm -> head, fused with the pixel-target MSE (HF:497-501,588-664)
     const RowMap tail{nmask, Lq, nvis};
@@ -558,8 +283,7 @@ int bvc_videomae_backward(bvc_ctx* c, const float* grad_loss, float* G, bvc_buck
     const bf16_t* W = c->wbf;
     const float* params = c->params;
     auto bucket = [&](int64_t lo, int64_t hi) { if (on_bucket) on_bucket(lo, hi - lo, user); };
-    c->seq = 0;
-    c->join_pending[0] = c->join_pending[1] = false;
+    begin_backward(c->w);
 
     BVC_CHECK_HIP(hipMemsetAsync(G, 0, (size_t)L.total * 4, st));
     // d loss / d logits = (2 / (Mm P)) * diff * grad_loss  - folded into alpha of the three head products
@@ -572,19 +296,19 @@ int bvc_videomae_backward(bvc_ctx* c, const float* grad_loss, float* G, bvc_buck
         TRY(launch_gemm(&p, 1, GEMM_TN, tile, st));
     }
     {
-        GemmProblem p = gemm(c->diff, (size_t)Mm * P, P, W + L.head_w, (size_t)P * Dd, Dd, Mm, Dd, P, EPI_BF16, c->dln, Dd);
+        GemmProblem p = gemm(c->diff, (size_t)Mm * P, P, W + L.head_w, (size_t)P * Dd, Dd, Mm, Dd, P, EPI_BF16, c->w.dln, Dd);
         p.alpha = cmse; p.alpha_dev = grad_loss;
         TRY(launch_gemm(&p, 1, GEMM_NN, -1, st));
     }
     // visible rows of the decoder stream receive no gradient from the head
     BVC_CHECK_HIP(hipMemsetAsync(c->dres_dec, 0, (size_t)Md * Dd * 4, st));
-    BVC_CHECK_HIP(hipMemsetAsync(c->dyb[0], 0, (size_t)Md * Dd * 2, st));
+    BVC_CHECK_HIP(hipMemsetAsync(c->w.dyb[0], 0, (size_t)Md * Dd * 2, st));
     const RowMap tail{nmask, Lq, nvis};
-    TRY(launch_ln_bwd(c->dln, c->dec.x_out, tail, c->meanf, c->rstdf, params + L.norm_w, c->dres_dec, 0, c->dyb[0],
-                      G + L.norm_w, G + L.norm_b, c->ln_part, Mm, Dd, st));
+    TRY(launch_ln_bwd(c->w.dln, c->dec.x_out, tail, c->meanf, c->rstdf, params + L.norm_w, c->dres_dec, 0, c->w.dyb[0],
+                      G + L.norm_w, G + L.norm_b, c->w.ln_part, Mm, Dd, st));
     bucket(L.norm_w, L.total);
     for (int i = c->dec.nlayers - 1; i >= 0; --i) {
-        TRY(layer_backward(c, c->dec, i, L.dec[i], c->dec.act[i].x_in, c->dres_dec, G, B, Lq, st, on_bucket, user));
+        TRY(layer_backward(c->w, c->dec, i, L.dec[i], c->dec.act[i].x_in, c->dres_dec, G, B, Lq, st, on_bucket, user));
     }
     // decoder input: mask token, encoder_to_decoder
     TRY(launch_colsum_f32(c->dres_dec, tail, Mm, Dd, G + L.mask_token, st));
@@ -597,23 +321,23 @@ int bvc_videomae_backward(bvc_ctx* c, const float* grad_loss, float* G, bvc_buck
     }
     {
         GemmProblem p = gemm(c->de2d, (size_t)Mv * Dd, Dd, W + L.e2d_w, (size_t)Dd * D, D, Mv, D, Dd, EPI_F32_BF16, c->dres_enc, D);
-        p.C2 = c->dyb[c->seq % 3];   // last read (as a dW operand) by backward step seq-3, fenced since
+        p.C2 = c->w.dyb[c->w.seq % 3];   // last read (as a dW operand) by backward step seq-3, fenced since
         TRY(launch_gemm(&p, 1, GEMM_NN, -1, st));
     }
     bucket(L.e2d_w, L.dec.front().ln1w);
     for (int i = c->enc.nlayers - 1; i >= 0; --i) {
-        TRY(layer_backward(c, c->enc, i, L.enc[i], c->enc.act[i].x_in, c->dres_enc, G, B, nvis, st, on_bucket, user));
+        TRY(layer_backward(c->w, c->enc, i, L.enc[i], c->enc.act[i].x_in, c->dres_enc, G, B, nvis, st, on_bucket, user));
     }
     // patch embedding: weight and bias only (pixels need no gradient)
     {
-        GemmProblem p = gemm(c->dyb[c->seq % 3], (size_t)Mv * D, D, c->Ape, (size_t)Mv * c->Kp, c->Kp, D, c->Kp, Mv, EPI_F32, G + L.pe_w, c->Kp);
+        GemmProblem p = gemm(c->w.dyb[c->w.seq % 3], (size_t)Mv * D, D, c->Ape, (size_t)Mv * c->Kp, c->Kp, D, c->Kp, Mv, EPI_F32, G + L.pe_w, c->Kp);
         p.rowsum = G + L.pe_b;
         const int tile = plan_dw(&p, 1);
         TRY(launch_gemm(&p, 1, GEMM_TN, tile, st));
     }
     // fence the last side-stream launches (older one first so ranges keep arriving tail-first)
-    TRY(join_side(c, c->seq & 1, st, on_bucket, user));
-    TRY(join_side(c, (c->seq + 1) & 1, st, on_bucket, user));
+    TRY(join_side(c->w, c->w.seq & 1, st, on_bucket, user));
+    TRY(join_side(c->w, (c->w.seq + 1) & 1, st, on_bucket, user));
     bucket(0, L.enc.front().ln1w);
     return BVC_OK;
 }
@@ -652,14 +376,15 @@ int bvc_op_gemm_num_tiles(const bvc_gemm_desc* problem, int tile_cfg) {
     if (!problem) return BVC_ERR_INVALID;
     return gemm_num_tiles(*problem, tile_cfg);
 }
-int bvc_op_attention_fwd(const void* qkv, void* ctx_out, float* lse, int B, int N, int H, void* stream) {
+int bvc_op_attention_fwd(const void* qkv, void* ctx_out, float* lse, int B, int N, int H, int head_dim, void* stream) {
     BVC_REQUIRE(qkv && ctx_out && lse, "op_attention_fwd: null argument");
-    return launch_attn_fwd((const bf16_t*)qkv, (bf16_t*)ctx_out, lse, B, N, H, (hipStream_t)stream);
+    return launch_attn_fwd((const bf16_t*)qkv, (bf16_t*)ctx_out, lse, B, N, H, head_dim, (hipStream_t)stream);
 }
 int bvc_op_attention_bwd(const void* qkv, const void* ctx_in, const void* dctx, const float* lse, float* delta, void* dqkv,
-                         int B, int N, int H, void* stream) {
+                         int B, int N, int H, int head_dim, void* stream) {
     BVC_REQUIRE(qkv && ctx_in && dctx && lse && delta && dqkv, "op_attention_bwd: null argument");
-    return launch_attn_bwd((const bf16_t*)qkv, (const bf16_t*)ctx_in, (const bf16_t*)dctx, lse, delta, (bf16_t*)dqkv, B, N, H, (hipStream_t)stream);
+    return launch_attn_bwd((const bf16_t*)qkv, (const bf16_t*)ctx_in, (const bf16_t*)dctx, lse, delta, (bf16_t*)dqkv, B, N, H, head_dim,
+                           (hipStream_t)stream);
 }
 int bvc_op_layernorm_fwd(const float* x, int rin, int rout, int roff, const float* gamma, const float* beta, void* y,
                          float* mean, float* rstd, int M, int D, float eps, void* stream) {

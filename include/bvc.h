@@ -119,10 +119,11 @@ typedef struct bvc_gemm_desc {
 int bvc_op_gemm(const bvc_gemm_desc* problems, int count, int layout, int tile_cfg, int stages, void* stream);
 int bvc_op_gemm_num_tiles(const bvc_gemm_desc* problem, int tile_cfg);
 
-/* softmax(QK^T/8)V for head_dim 64; qkv bf16 [B*N][3*64*H]; replaces HF:181-206 / SDPA (HF:239-252) */
-int bvc_op_attention_fwd(const void* qkv, void* ctx_out, float* lse, int B, int N, int H, void* stream);
+/* softmax(QK^T/sqrt(d))V for head_dim d = 64 or 32; qkv bf16 [B*N][3*d*H]; replaces HF:181-206 / SDPA (HF:239-252) and
+ * Attention.forward of pretraining/predictive/vision_transformer.py:198-210 (the ViT-B predictor has d = 32) */
+int bvc_op_attention_fwd(const void* qkv, void* ctx_out, float* lse, int B, int N, int H, int head_dim, void* stream);
 int bvc_op_attention_bwd(const void* qkv, const void* ctx_in, const void* dctx, const float* lse, float* delta_scratch,
-                         void* dqkv, int B, int N, int H, void* stream);
+                         void* dqkv, int B, int N, int H, int head_dim, void* stream);
 /* nn.LayerNorm forward/backward (HF:336-337,484); rows may be strided by (rin, rout, roff), rin<=0 = dense */
 int bvc_op_layernorm_fwd(const float* x, int rin, int rout, int roff, const float* gamma, const float* beta, void* y_bf16,
                          float* mean, float* rstd, int M, int D, float eps, void* stream);

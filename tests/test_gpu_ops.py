@@ -200,46 +200,48 @@ def test_gemm_epilogues():
 
 
 # --------------------------------------------------------------------------- attention
-def _ref_attention(qkv, B, N, H):
-    D = 64 * H
-    x = qkv.float().view(B, N, 3, H, 64).permute(2, 0, 3, 1, 4)
+def _ref_attention(qkv, B, N, H, HD=64):
+    D = HD * H
+    x = qkv.float().view(B, N, 3, H, HD).permute(2, 0, 3, 1, 4)
     q, k, v = x[0], x[1], x[2]
-    s = (q @ k.transpose(-1, -2)) * 0.125
+    s = (q @ k.transpose(-1, -2)) * HD ** -0.5
     p = torch.softmax(s, dim=-1)
     o = (p @ v).transpose(1, 2).reshape(B * N, D)
     lse2 = torch.logsumexp(s, dim=-1) * math.log2(math.e)
     return o, lse2.reshape(B * H, N)
 
 
-@pytest.mark.parametrize("B,N,H", [(2, 160, 2), (1, 1568, 2), (3, 100, 1), (2, 24, 1), (1, 392, 3)])
-def test_attention_forward(B, N, H):
-    D = 64 * H
+@pytest.mark.parametrize("HD", [64, 32])
+@pytest.mark.parametrize("B,N,H", [(2, 160, 2), (1, 1568, 2), (3, 100, 1), (2, 24, 1), (1, 392, 3), (4, 108, 12)])
+def test_attention_forward(B, N, H, HD):
+    D = HD * H
     qkv = G.bf16_randn(B * N, 3 * D, seed=30)
     ctx = torch.zeros(B * N, D, device=dev, dtype=torch.bfloat16)
     lse = torch.zeros(B * H, N, device=dev)
-    L.check(L.lib().bvc_op_attention_fwd(G.ptr(qkv), G.ptr(ctx), G.ptr(lse), B, N, H, G.stream()), "attention_fwd")
+    L.check(L.lib().bvc_op_attention_fwd(G.ptr(qkv), G.ptr(ctx), G.ptr(lse), B, N, H, HD, G.stream()), "attention_fwd")
     torch.cuda.synchronize()
-    o, lse2 = _ref_attention(qkv, B, N, H)
+    o, lse2 = _ref_attention(qkv, B, N, H, HD)
     # P is rounded to bf16 before P V and the output is bf16: 1e-2 relative L2
     assert G.rel_err(ctx.float(), o) < 1e-2, G.rel_err(ctx.float(), o)
     assert float((lse - lse2).abs().max()) < 2e-3
 
 
-@pytest.mark.parametrize("B,N,H", [(2, 160, 2), (1, 1568, 1), (3, 100, 1), (2, 24, 1)])
-def test_attention_backward(B, N, H):
-    D = 64 * H
+@pytest.mark.parametrize("HD", [64, 32])
+@pytest.mark.parametrize("B,N,H", [(2, 160, 2), (1, 1568, 1), (3, 100, 1), (2, 24, 1), (4, 108, 12)])
+def test_attention_backward(B, N, H, HD):
+    D = HD * H
     qkv = G.bf16_randn(B * N, 3 * D, seed=31)
     dctx = G.bf16_randn(B * N, D, seed=32)
     ctx = torch.zeros(B * N, D, device=dev, dtype=torch.bfloat16)
     lse = torch.zeros(B * H, N, device=dev)
-    L.check(L.lib().bvc_op_attention_fwd(G.ptr(qkv), G.ptr(ctx), G.ptr(lse), B, N, H, G.stream()), "attention_fwd")
+    L.check(L.lib().bvc_op_attention_fwd(G.ptr(qkv), G.ptr(ctx), G.ptr(lse), B, N, H, HD, G.stream()), "attention_fwd")
     dqkv = torch.full((B * N, 3 * D), float("nan"), device=dev, dtype=torch.bfloat16)
     delta = torch.zeros(B * H, N, device=dev)
     L.check(L.lib().bvc_op_attention_bwd(G.ptr(qkv), G.ptr(ctx), G.ptr(dctx), G.ptr(lse), G.ptr(delta), G.ptr(dqkv),
-                                         B, N, H, G.stream()), "attention_bwd")
+                                         B, N, H, HD, G.stream()), "attention_bwd")
     torch.cuda.synchronize()
     x = qkv.float().requires_grad_(True)
-    o, _ = _ref_attention(x, B, N, H)
+    o, _ = _ref_attention(x, B, N, H, HD)
     (o * dctx.float()).sum().backward()
     got, ref = dqkv.float(), x.grad
     assert torch.isfinite(got).all()
@@ -250,7 +252,7 @@ def test_attention_backward(B, N, H):
 
 def test_attention_sharp_softmax():
     # one key dominates each row: exercises the running-max update across key tiles
-    B, N, H = 1, 200, 1
+    B, N, H, HD = 1, 200, 1, 64
     g = torch.Generator().manual_seed(5)
     q = torch.randn(N, 64, generator=g) * 4
     k = torch.randn(N, 64, generator=g) * 4
@@ -258,7 +260,7 @@ def test_attention_sharp_softmax():
     qkv = torch.cat([q, k, v], dim=1).to(torch.bfloat16).to(dev)
     ctx = torch.zeros(N, 64, device=dev, dtype=torch.bfloat16)
     lse = torch.zeros(1, N, device=dev)
-    L.check(L.lib().bvc_op_attention_fwd(G.ptr(qkv), G.ptr(ctx), G.ptr(lse), B, N, H, G.stream()), "attention_fwd")
+    L.check(L.lib().bvc_op_attention_fwd(G.ptr(qkv), G.ptr(ctx), G.ptr(lse), B, N, H, HD, G.stream()), "attention_fwd")
     torch.cuda.synchronize()
     o, lse2 = _ref_attention(qkv, B, N, H)
     assert G.rel_err(ctx.float(), o) < 1e-2

@@ -5,8 +5,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from tests import gpu_util as G
 L = G.L
-B, N, H = 16, 1568, 6
-D = 64 * H
+B, N, H, HD = 16, 1568, 6, 64
+D = HD * H
 qkv = G.bf16_randn(B * N, 3 * D)
 ctx = torch.zeros(B * N, D, device="cuda", dtype=torch.bfloat16)
 lse = torch.zeros(B * H, N, device="cuda")
@@ -14,6 +14,6 @@ dctx = G.bf16_randn(B * N, D, seed=2)
 dqkv = torch.zeros_like(qkv)
 delta = torch.zeros(B * H, N, device="cuda")
 for _ in range(3):
-    L.check(L.lib().bvc_op_attention_fwd(G.ptr(qkv), G.ptr(ctx), G.ptr(lse), B, N, H, G.stream()))
-    L.check(L.lib().bvc_op_attention_bwd(G.ptr(qkv), G.ptr(ctx), G.ptr(dctx), G.ptr(lse), G.ptr(delta), G.ptr(dqkv), B, N, H, G.stream()))
+    L.check(L.lib().bvc_op_attention_fwd(G.ptr(qkv), G.ptr(ctx), G.ptr(lse), B, N, H, HD, G.stream()))
+    L.check(L.lib().bvc_op_attention_bwd(G.ptr(qkv), G.ptr(ctx), G.ptr(dctx), G.ptr(lse), G.ptr(delta), G.ptr(dqkv), B, N, H, HD, G.stream()))
 torch.cuda.synchronize()

@@ -42,18 +42,18 @@ def gemm_case(name, layout, M, N, K, tile=-1, split=1, epi="BF16", stages=-1):
             "ms": round(ms, 4), "tflops": round(tf, 1)}
 
 
-def attn_case(B, N, H):
-    D = 64 * H
+def attn_case(B, N, H, HD=64):
+    D = HD * H
     qkv = G.bf16_randn(B * N, 3 * D)
     ctx = torch.zeros(B * N, D, device=dev, dtype=torch.bfloat16)
     lse = torch.zeros(B * H, N, device=dev)
     dctx = G.bf16_randn(B * N, D, seed=2)
     dqkv = torch.zeros_like(qkv)
     delta = torch.zeros(B * H, N, device=dev)
-    f = lambda: L.check(L.lib().bvc_op_attention_fwd(G.ptr(qkv), G.ptr(ctx), G.ptr(lse), B, N, H, G.stream()))
-    b = lambda: L.check(L.lib().bvc_op_attention_bwd(G.ptr(qkv), G.ptr(ctx), G.ptr(dctx), G.ptr(lse), G.ptr(delta), G.ptr(dqkv), B, N, H, G.stream()))
+    f = lambda: L.check(L.lib().bvc_op_attention_fwd(G.ptr(qkv), G.ptr(ctx), G.ptr(lse), B, N, H, HD, G.stream()))
+    b = lambda: L.check(L.lib().bvc_op_attention_bwd(G.ptr(qkv), G.ptr(ctx), G.ptr(dctx), G.ptr(lse), G.ptr(delta), G.ptr(dqkv), B, N, H, HD, G.stream()))
     mf, mb = timeit(f), timeit(b)
-    flops = 4.0 * B * H * N * N * 64
+    flops = 4.0 * B * H * N * N * HD
     return {"name": f"attn B{B} N{N} H{H}", "fwd_ms": round(mf, 4), "fwd_tflops": round(flops / (mf * 1e-3) / 1e12, 1),
             "bwd_ms": round(mb, 4), "bwd_tflops_5prod": round(2.5 * flops / (mb * 1e-3) / 1e12, 1)}
 

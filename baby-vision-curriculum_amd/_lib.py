@@ -24,6 +24,15 @@ class VideoMAEConfigC(ctypes.Structure):
                                          ("norm_pix_loss", c_int)]
 
 
+class VitConfigC(ctypes.Structure):
+    _fields_ = [(n, c_int) for n in ("image_size", "patch_size", "num_channels", "num_frames", "tubelet_size", "embed_dim",
+                                     "depth", "num_heads", "mlp_hidden")] + [("eps", c_float)]
+
+
+class PredictorConfigC(ctypes.Structure):
+    _fields_ = [(n, c_int) for n in ("seq_len", "embed_dim", "pred_dim", "depth", "num_heads", "mlp_hidden")] + [("eps", c_float)]
+
+
 class GemmDesc(ctypes.Structure):
     _fields_ = [
         ("A", c_void_p), ("B", c_void_p),
@@ -55,6 +64,27 @@ SYMBOLS = {
     "bvc_videomae_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "bvc_videomae_backward": (c_int, [c_void_p, c_void_p, c_void_p, BUCKET_FN, c_void_p, c_void_p]),
     "bvc_videomae_tap": (c_int, [c_void_p, c_char_p, c_void_p, c_int64, ctypes.POINTER(c_int64), c_void_p]),
+    "bvc_vit_param_count": (c_int, [ctypes.POINTER(VitConfigC)]),
+    "bvc_vit_param_numel": (c_int64, [ctypes.POINTER(VitConfigC)]),
+    "bvc_vit_param_info": (c_int, [ctypes.POINTER(VitConfigC), c_int, ctypes.c_char_p, c_int, ctypes.POINTER(c_int64),
+                                   ctypes.POINTER(c_int64), ctypes.POINTER(c_int), ctypes.POINTER(c_int64)]),
+    "bvc_vit_create": (c_int, [ctypes.POINTER(VitConfigC), c_int, ctypes.POINTER(c_void_p)]),
+    "bvc_vit_destroy": (None, [c_void_p]),
+    "bvc_vit_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "bvc_vit_backward": (c_int, [c_void_p, c_void_p, c_void_p, BUCKET_FN, c_void_p, c_void_p]),
+    "bvc_predictor_param_count": (c_int, [ctypes.POINTER(PredictorConfigC)]),
+    "bvc_predictor_param_numel": (c_int64, [ctypes.POINTER(PredictorConfigC)]),
+    "bvc_predictor_param_info": (c_int, [ctypes.POINTER(PredictorConfigC), c_int, ctypes.c_char_p, c_int, ctypes.POINTER(c_int64),
+                                         ctypes.POINTER(c_int64), ctypes.POINTER(c_int), ctypes.POINTER(c_int64)]),
+    "bvc_predictor_create": (c_int, [ctypes.POINTER(PredictorConfigC), c_int, c_int, c_int, ctypes.POINTER(c_void_p)]),
+    "bvc_predictor_destroy": (None, [c_void_p]),
+    "bvc_predictor_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "bvc_predictor_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "bvc_op_target_select": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    "bvc_op_smooth_l1_workspace": (c_int, [c_int64]),
+    "bvc_op_smooth_l1_fwd": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
+    "bvc_op_smooth_l1_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
+    "bvc_op_ema": (c_int, [c_void_p, c_void_p, c_int64, c_float, c_void_p]),
     "bvc_op_gemm": (c_int, [ctypes.POINTER(GemmDesc), c_int, c_int, c_int, c_int, c_void_p]),
     "bvc_op_gemm_num_tiles": (c_int, [ctypes.POINTER(GemmDesc), c_int]),
     "bvc_op_attention_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),

@@ -12,8 +12,9 @@ static inline RowMap identity_rows() { return RowMap{0, 0, 0}; }
 // clip f32 [B][T][C][H][W]; tubes of ts frames x ps x ps pixels
 struct PatchGeom { int T, C, H, W, ts, ps; };
 
+// gamma == nullptr: no affine.  y (bf16) and/or y32 (f32) receive the result; mean / rstd may be null.
 int launch_ln_fwd(const float* x, RowMap rm, const float* gamma, const float* beta, bf16_t* y, float* mean, float* rstd,
-                  int M, int D, float eps, hipStream_t s);
+                  int M, int D, float eps, hipStream_t s, float* y32 = nullptr);
 // `part` = scratch of ln_bwd_workspace_floats(M, D) floats (per-workgroup dgamma / dbeta partials)
 size_t ln_bwd_workspace_floats(int M, int D);
 size_t ln_bwd_workspace_floats_upto(int Mmax, int D);
@@ -34,6 +35,15 @@ int launch_sgd_step(float* p, float* g, float* buf, size_t n, float lr, float mo
 int launch_row_normalize(const float* f, bf16_t* fn, float* inv, int n, int p, float eps, hipStream_t s);
 int launch_row_normalize_bwd(const float* f, const float* inv, const float* dfn, float* df, int n, int p, hipStream_t s);
 int launch_nce_finalize(const float* partial, int ntiles, float inv_t, double npos, float* loss, float* stats, hipStream_t s);
+int launch_target_select(const float* h, const int* idx, float* out, int nsets, int B, int Np, int L, int D, float eps, hipStream_t s);
+int launch_pred_assemble(const float* xe, const float* mask_token, const float* pos, const int* idx_pred, float* X, int nsets, int B,
+                         int Nc, int Np, int D, hipStream_t s);
+int launch_pred_ctx_grad(const float* dX, bf16_t* dxe, int nsets, int B, int Nc, int Np, int D, hipStream_t s);
+int smooth_l1_blocks(size_t n);
+int launch_smooth_l1_fwd(const float* z, const float* h, size_t n, float* partial, float* loss, hipStream_t s);
+int launch_smooth_l1_bwd(const float* z, const float* h, const float* gout, size_t n, float* dz, hipStream_t s);
+int launch_ema(float* k, const float* q, size_t n, float m, hipStream_t s);
+int launch_iota_mod(int* idx, int n, int L, hipStream_t s);
 int launch_loss_finalize(const float* partial, int n, double count, const int* status, float* loss, hipStream_t s);
 
 }  // namespace bvc

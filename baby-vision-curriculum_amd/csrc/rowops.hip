@@ -3,6 +3,8 @@
 // input fill, loss finalize.  All are one-pass streaming kernels with 8-16 B per lane accesses.
 #include "rowops.h"
 
+#include <algorithm>
+
 namespace bvc {
 
 constexpr int kMaxChunks = 4;   // float4 chunks per lane: D <= 1024
@@ -15,7 +17,7 @@ __device__ __forceinline__ int map_row(int m, RowMap rm) {
 // one wave per row; y = (x - mean) * rstd * gamma + beta in bf16; saves mean / rstd (biased variance,
 // torch.nn.LayerNorm semantics, HF:336-337)
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, RowMap rm, const float* __restrict__ gamma,
-                                                     const float* __restrict__ beta, bf16_t* __restrict__ y,
+                                                     const float* __restrict__ beta, bf16_t* __restrict__ y, float* __restrict__ y32,
                                                      float* __restrict__ mean, float* __restrict__ rstd, int M, int D, float eps) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int m = blockIdx.x * 4 + wave;
@@ -40,16 +42,17 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
         }
     }
     const float rs = rsqrtf(wave_sum(q) / D + eps);
-    if (lane == 0) { mean[m] = mu; rstd[m] = rs; }
-    uint2* yr = reinterpret_cast<uint2*>(y + (size_t)m * D);
+    if (lane == 0 && mean) { mean[m] = mu; rstd[m] = rs; }
+    uint2* yr = y ? reinterpret_cast<uint2*>(y + (size_t)m * D) : nullptr;
+    f32x4* yf = y32 ? reinterpret_cast<f32x4*>(y32 + (size_t)m * D) : nullptr;
 #pragma unroll
     for (int i = 0; i < kMaxChunks; ++i) {
         const int c = lane + 64 * i;
         if (c < nch) {
-            const f32x4 g = reinterpret_cast<const f32x4*>(gamma)[c];
-            const f32x4 b = reinterpret_cast<const f32x4*>(beta)[c];
-            const f32x4 o = (v[i] - mu) * rs * g + b;
-            yr[c] = uint2{pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
+            f32x4 o = (v[i] - mu) * rs;
+            if (gamma) o = o * reinterpret_cast<const f32x4*>(gamma)[c] + reinterpret_cast<const f32x4*>(beta)[c];
+            if (yr) yr[c] = uint2{pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
+            if (yf) yf[c] = o;
         }
     }
 }
@@ -329,6 +332,128 @@ __global__ __launch_bounds__(256) void loss_finalize_kernel(const float* __restr
     if (threadIdx.x == 0) *loss = (status && *status) ? __int_as_float(0x7fc00000) : (float)(red[0] / count);
 }
 
+// ============================================================================ JEPA pieces
+// token gather with an index list: logical row m of a [nsets*B*n] output reads x[(b*L + idx[m])] where b = (m / n) % B;
+// used as RowGather in the target selection below
+// targets (pretrain_jepa.py:384-392): h = layer_norm(target_encoder(imgs)) without affine, rows picked by the 4 prediction
+// masks, set-major then sample:  out[(i*B + b)*Np + j] = LN(h[b*L + idx[(i*B + b)*Np + j]]).  One wave per row.
+__global__ __launch_bounds__(256) void target_select_kernel(const float* __restrict__ h, const int* __restrict__ idx,
+                                                            float* __restrict__ out, int rows, int B, int Np, int L, int D, float eps) {
+    const int lane = threadIdx.x & 63, m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= rows) return;
+    const int b = (m / Np) % B;
+    const f32x4* xr = reinterpret_cast<const f32x4*>(h + ((size_t)b * L + idx[m]) * D);
+    const int nch = D >> 2;
+    f32x4 v[kMaxChunks];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < kMaxChunks; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nch) { v[i] = xr[c]; s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]); }
+    }
+    const float mu = wave_sum(s) / D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < kMaxChunks; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nch) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mu; q += d * d; }
+        }
+    }
+    const float rs = rsqrtf(wave_sum(q) / D + eps);
+    f32x4* o = reinterpret_cast<f32x4*>(out + (size_t)m * D);
+#pragma unroll
+    for (int i = 0; i < kMaxChunks; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nch) o[c] = (v[i] - mu) * rs;
+    }
+}
+
+// predictor input (vision_transformer.py:507-524): sequence s = i*B + b is [ctx tokens of sample b ; mask_token + pos[pred idx]]
+__global__ void pred_assemble_kernel(const float* __restrict__ xe, const float* __restrict__ mask_token, const float* __restrict__ pos,
+                                     const int* __restrict__ idx_pred, float* __restrict__ X, int nseq, int B, int Nc, int Np, int D) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int nch = D >> 2, T = Nc + Np;
+    if (i >= (size_t)nseq * T * nch) return;
+    const int c = (int)(i % nch);
+    const int t = (int)((i / nch) % T), sq = (int)(i / ((size_t)nch * T));
+    f32x4 v;
+    if (t < Nc) {
+        v = reinterpret_cast<const f32x4*>(xe + ((size_t)(sq % B) * Nc + t) * D)[c];
+    } else {
+        v = reinterpret_cast<const f32x4*>(mask_token)[c] + reinterpret_cast<const f32x4*>(pos + (size_t)idx_pred[(size_t)sq * Np + (t - Nc)] * D)[c];
+    }
+    reinterpret_cast<f32x4*>(X + ((size_t)sq * T + t) * D)[c] = v;
+}
+
+// gradient of the replicated context tokens: dxe[b*Nc + t] = sum_i dX[(i*B + b)][t]  -> bf16 (GEMM operand)
+__global__ void pred_ctx_grad_kernel(const float* __restrict__ dX, bf16_t* __restrict__ dxe, int nsets, int B, int Nc, int Np, int D) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int nch = D >> 2, T = Nc + Np;
+    if (i >= (size_t)B * Nc * nch) return;
+    const int c = (int)(i % nch);
+    const int t = (int)((i / nch) % Nc), b = (int)(i / ((size_t)nch * Nc));
+    f32x4 a = {0, 0, 0, 0};
+    for (int k = 0; k < nsets; ++k) a += reinterpret_cast<const f32x4*>(dX + (((size_t)k * B + b) * T + t) * D)[c];
+    reinterpret_cast<uint2*>(dxe + ((size_t)b * Nc + t) * D)[c] = uint2{pack2bf(a[0], a[1]), pack2bf(a[2], a[3])};
+}
+
+// smooth-L1 (beta = 1, mean; pretrain_jepa.py:399-402): per-block partial sums, folded by loss_finalize_kernel
+__global__ __launch_bounds__(256) void smooth_l1_fwd_kernel(const float* __restrict__ z, const float* __restrict__ h, size_t n,
+                                                            float* __restrict__ partial) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (size_t)gridDim.x * 1024) {
+        if (i + 4 <= n) {
+            const f32x4 d = *reinterpret_cast<const f32x4*>(z + i) - *reinterpret_cast<const f32x4*>(h + i);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float a = fabsf(d[e]); s += a < 1.f ? 0.5f * a * a : a - 0.5f; }
+        } else {
+            for (size_t j = i; j < n; ++j) { const float a = fabsf(z[j] - h[j]); s += a < 1.f ? 0.5f * a * a : a - 0.5f; }
+        }
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// dz = gout / n * clamp(z - h, -1, 1)
+__global__ void smooth_l1_bwd_kernel(const float* __restrict__ z, const float* __restrict__ h, const float* __restrict__ gout,
+                                     size_t n, float* __restrict__ dz) {
+    const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i >= n) return;
+    const float g = gout[0] / (float)n;
+    if (i + 4 <= n) {
+        const f32x4 d = *reinterpret_cast<const f32x4*>(z + i) - *reinterpret_cast<const f32x4*>(h + i);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = g * fminf(fmaxf(d[e], -1.f), 1.f);
+        *reinterpret_cast<f32x4*>(dz + i) = o;
+    } else {
+        for (size_t j = i; j < n; ++j) dz[j] = g * fminf(fmaxf(z[j] - h[j], -1.f), 1.f);
+    }
+}
+
+// momentum update of the target encoder (pretrain_jepa.py:426-432): k = m * k + (1 - m) * q over a flat range
+__global__ void ema_kernel(float* __restrict__ k, const float* __restrict__ q, size_t n, float m) {
+    const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i >= n) return;
+    if (i + 4 <= n) {
+        const f32x4 kv = *reinterpret_cast<f32x4*>(k + i), qv = *reinterpret_cast<const f32x4*>(q + i);
+        *reinterpret_cast<f32x4*>(k + i) = kv * m + qv * (1.f - m);
+    } else {
+        for (size_t j = i; j < n; ++j) k[j] = k[j] * m + q[j] * (1.f - m);
+    }
+}
+
+// idx[b*L + t] = t  (identity token list: "all tokens" for the target encoder)
+__global__ void iota_mod_kernel(int* __restrict__ idx, int n, int L) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) idx[i] = i % L;
+}
+
 // ============================================================================ SimCLR loss pieces
 // fn = f / max(||f||, eps) in bf16 (operand of the similarity GEMM), inv[i] = 1 / max(||f_i||, eps);
 // F.cosine_similarity semantics (pretraining/contrastive/pretrain_simclr.py:116).  One wave per row.
@@ -429,9 +554,9 @@ __global__ void sgd_step_kernel(float* __restrict__ p, float* __restrict__ g, fl
 static inline unsigned blocks_for(size_t items, int per = 256) { return (unsigned)((items + per - 1) / per); }
 
 int launch_ln_fwd(const float* x, RowMap rm, const float* gamma, const float* beta, bf16_t* y, float* mean, float* rstd,
-                  int M, int D, float eps, hipStream_t s) {
+                  int M, int D, float eps, hipStream_t s, float* y32) {
     BVC_REQUIRE(D % 4 == 0 && D <= kMaxChunks * 256, "ln_fwd: D=%d unsupported", D);
-    hipLaunchKernelGGL(ln_fwd_kernel, dim3((M + 3) / 4), dim3(256), 0, s, x, rm, gamma, beta, y, mean, rstd, M, D, eps);
+    hipLaunchKernelGGL(ln_fwd_kernel, dim3((M + 3) / 4), dim3(256), 0, s, x, rm, gamma, beta, y, y32, mean, rstd, M, D, eps);
     BVC_CHECK_HIP(hipGetLastError());
     return BVC_OK;
 }
@@ -525,6 +650,57 @@ int launch_labels(const float* clip, const int* msk_idx, float* labels, int B, i
 int launch_fill_masked(float* xfull, const float* mask_token, const float* pos, const int* msk_idx, int B, int L, int nvis,
                        int nmask, int D, hipStream_t s) {
     hipLaunchKernelGGL(fill_masked_kernel, dim3(blocks_for((size_t)B * nmask * (D / 4))), dim3(256), 0, s, xfull, mask_token, pos, msk_idx, B, L, nvis, nmask, D);
+    BVC_CHECK_HIP(hipGetLastError());
+    return BVC_OK;
+}
+
+int launch_target_select(const float* h, const int* idx, float* out, int nsets, int B, int Np, int L, int D, float eps, hipStream_t s) {
+    BVC_REQUIRE(D % 4 == 0 && D <= kMaxChunks * 256, "target_select: D=%d unsupported", D);
+    const int rows = nsets * B * Np;
+    hipLaunchKernelGGL(target_select_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, h, idx, out, rows, B, Np, L, D, eps);
+    BVC_CHECK_HIP(hipGetLastError());
+    return BVC_OK;
+}
+
+int launch_pred_assemble(const float* xe, const float* mask_token, const float* pos, const int* idx_pred, float* X, int nsets, int B,
+                         int Nc, int Np, int D, hipStream_t s) {
+    const size_t items = (size_t)nsets * B * (Nc + Np) * (D / 4);
+    hipLaunchKernelGGL(pred_assemble_kernel, dim3(blocks_for(items)), dim3(256), 0, s, xe, mask_token, pos, idx_pred, X, nsets * B, B, Nc, Np, D);
+    BVC_CHECK_HIP(hipGetLastError());
+    return BVC_OK;
+}
+
+int launch_pred_ctx_grad(const float* dX, bf16_t* dxe, int nsets, int B, int Nc, int Np, int D, hipStream_t s) {
+    hipLaunchKernelGGL(pred_ctx_grad_kernel, dim3(blocks_for((size_t)B * Nc * (D / 4))), dim3(256), 0, s, dX, dxe, nsets, B, Nc, Np, D);
+    BVC_CHECK_HIP(hipGetLastError());
+    return BVC_OK;
+}
+
+int smooth_l1_blocks(size_t n) { return (int)std::min<size_t>(1024, (n + 1023) / 1024); }
+
+int launch_smooth_l1_fwd(const float* z, const float* h, size_t n, float* partial, float* loss, hipStream_t s) {
+    BVC_REQUIRE(n > 0, "smooth_l1: empty input");
+    const int nb = smooth_l1_blocks(n);
+    hipLaunchKernelGGL(smooth_l1_fwd_kernel, dim3(nb), dim3(256), 0, s, z, h, n, partial);
+    BVC_CHECK_HIP(hipGetLastError());
+    return launch_loss_finalize(partial, nb, (double)n, nullptr, loss, s);
+}
+
+int launch_smooth_l1_bwd(const float* z, const float* h, const float* gout, size_t n, float* dz, hipStream_t s) {
+    hipLaunchKernelGGL(smooth_l1_bwd_kernel, dim3(blocks_for((n + 3) / 4)), dim3(256), 0, s, z, h, gout, n, dz);
+    BVC_CHECK_HIP(hipGetLastError());
+    return BVC_OK;
+}
+
+int launch_ema(float* k, const float* q, size_t n, float m, hipStream_t s) {
+    if (n == 0) return BVC_OK;
+    hipLaunchKernelGGL(ema_kernel, dim3(blocks_for((n + 3) / 4)), dim3(256), 0, s, k, q, n, m);
+    BVC_CHECK_HIP(hipGetLastError());
+    return BVC_OK;
+}
+
+int launch_iota_mod(int* idx, int n, int L, hipStream_t s) {
+    hipLaunchKernelGGL(iota_mod_kernel, dim3(blocks_for((size_t)n)), dim3(256), 0, s, idx, n, L);
     BVC_CHECK_HIP(hipGetLastError());
     return BVC_OK;
 }

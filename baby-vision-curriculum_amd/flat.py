@@ -1,0 +1,144 @@
+"""nn.Module whose parameters are views into ONE flat f32 buffer laid out by libbvc_hip.so.
+
+The library reports (state-dict key, offset, shape) triples; every ``nn.Parameter`` (and, after a backward, every
+``.grad``) is a view of a contiguous buffer, so the cast to bf16, the optimiser update and the data-parallel
+all-reduce are single large transfers while ``state_dict()``, ``parameters()``, ``GradScaler`` and ``grad_logger``
+keep working with the reference's key names.
+"""
+import ctypes
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+
+def query_layout(count_fn, numel_fn, info_fn, cfg_c):
+    n = count_fn(ctypes.byref(cfg_c))
+    if n <= 0:
+        _lib.check(n if n < 0 else -1, "param_count")
+    out = []
+    name = ctypes.create_string_buffer(256)
+    off, numel, ndim = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int()
+    shape = (ctypes.c_int64 * 5)()
+    for i in range(n):
+        _lib.check(info_fn(ctypes.byref(cfg_c), i, name, 256, ctypes.byref(off), ctypes.byref(numel), ctypes.byref(ndim), shape),
+                   "param_info")
+        out.append((name.value.decode(), int(off.value), tuple(int(shape[j]) for j in range(ndim.value))))
+    return out, int(numel_fn(ctypes.byref(cfg_c)))
+
+
+class FlatParamModule(nn.Module):
+    def _init_flat(self, layout, numel, init_fn, frozen=()):
+        """layout: [(dotted name, offset, shape)]; init_fn(name, shape) -> tensor; frozen: names with requires_grad=False."""
+        self._layout, self._numel = layout, numel
+        self._names = []
+        for name, _off, shape in layout:
+            self._register(name, nn.Parameter(init_fn(name, shape), requires_grad=name not in frozen))
+            self._names.append(name)
+        self._flat = None
+        self._flat_grad = None
+        self._bucket_hook = None      # set by the data-parallel wrapper: fn(offset, count)
+        self._after_backward = None
+
+    def _register(self, dotted, param):
+        mod = self
+        parts = dotted.split(".")
+        for p in parts[:-1]:
+            if p not in mod._modules:
+                mod.add_module(p, nn.Module())
+            mod = mod._modules[p]
+        mod.register_parameter(parts[-1], param)
+
+    def _param(self, dotted):
+        mod = self
+        parts = dotted.split(".")
+        for p in parts[:-1]:
+            mod = mod._modules[p]
+        return mod._parameters[parts[-1]]
+
+    def _ensure_flat(self, device):
+        """(Re)pack the parameters into one contiguous buffer in the library's layout, e.g. after .to() / deepcopy."""
+        flat = self._flat
+        ok = flat is not None and flat.device == device
+        if ok:
+            base = flat.data_ptr()
+            for name, off, _shape in self._layout:
+                if self._param(name).data_ptr() != base + 4 * off:
+                    ok = False
+                    break
+        if ok:
+            return
+        new = torch.empty(self._numel, dtype=torch.float32, device=device)
+        for name, off, shape in self._layout:
+            p = self._param(name)
+            n = p.numel()
+            new[off:off + n].copy_(p.data.reshape(-1).to(device=device, dtype=torch.float32))
+            p.data = new[off:off + n].view(shape)
+            p.grad = None
+        self._flat = new
+        self._flat_grad = None
+
+    def flat_parameters(self):
+        if self._flat is None:
+            raise RuntimeError("parameters are flattened on the first forward on a GPU (or call _ensure_flat(device))")
+        return self._flat
+
+    def flat_grads(self):
+        if self._flat_grad is None:
+            self._flat_grad = torch.zeros_like(self.flat_parameters())
+        return self._flat_grad
+
+    def __deepcopy__(self, memo):
+        # copy.deepcopy(encoder) (pretrain_jepa.py:258): views of a shared buffer do not survive the default deepcopy
+        import copy
+        cls = self.__class__
+        new = cls.__new__(cls)
+        memo[id(self)] = new
+        nn.Module.__init__(new)
+        for k, v in self.__dict__.items():
+            if k in ("_parameters", "_modules", "_buffers", "_flat", "_flat_grad", "_ctx", "_ctx_key", "_live", "_bucket_hook",
+                     "_after_backward") or k.startswith("_forward_") or k.startswith("_backward_") or k.startswith("_state_dict") \
+                    or k.startswith("_load_state_dict"):
+                continue
+            new.__dict__[k] = copy.deepcopy(v, memo)
+        new._flat = new._flat_grad = None
+        new._bucket_hook = new._after_backward = None
+        if hasattr(self, "_ctx"):
+            new._ctx, new._ctx_key = None, None
+        for name, _off, _shape in self._layout:
+            p = self._param(name)
+            new._register(name, nn.Parameter(p.detach().clone(), requires_grad=p.requires_grad))
+        new.train(self.training)
+        return new
+
+    def _grad_target(self):
+        """(buffer to write gradients into, accumulate?)  Fresh gradients go straight into the flat buffer."""
+        G = self.flat_grads()
+        live = [self._param(n) for n in (self._names[0], self._names[-1])]
+        accumulate = any(p.grad is not None for p in live)
+        return (torch.empty_like(G) if accumulate else G), accumulate
+
+    def _publish_grads(self, target, accumulate):
+        G = self.flat_grads()
+        if accumulate:
+            G.add_(target)
+            if self._bucket_hook is not None:
+                self._bucket_hook(0, self._numel)
+        else:
+            for name, off, shape in self._layout:
+                p = self._param(name)
+                if p.requires_grad:
+                    n = p.numel()
+                    p.grad = G[off:off + n].view(shape)
+        if self._after_backward is not None:
+            self._after_backward()
+
+    def _bucket_callback(self, accumulate):
+        hook = self._bucket_hook if not accumulate else None
+        if hook is None:
+            return ctypes.cast(None, _lib.BUCKET_FN)
+
+        def _cb(offset, count, _user, _hook=hook):
+            _hook(int(offset), int(count))
+        return _lib.BUCKET_FN(_cb)

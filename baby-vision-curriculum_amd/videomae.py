@@ -20,6 +20,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
+from .flat import FlatParamModule, query_layout
 
 
 class VideoMAEConfig:
@@ -72,19 +73,7 @@ class VideoMAEForPreTrainingOutput:
 def param_layout(config: VideoMAEConfig):
     """[(state-dict key, offset, shape)] in flat-buffer order, as libbvc_hip.so defines it."""
     L = _lib.lib()
-    cc = config.to_c()
-    n = L.bvc_videomae_param_count(ctypes.byref(cc))
-    if n <= 0:
-        _lib.check(n if n < 0 else -1, "bvc_videomae_param_count")
-    out = []
-    name = ctypes.create_string_buffer(256)
-    off, numel, ndim = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int()
-    shape = (ctypes.c_int64 * 5)()
-    for i in range(n):
-        _lib.check(L.bvc_videomae_param_info(ctypes.byref(cc), i, name, 256, ctypes.byref(off), ctypes.byref(numel),
-                                             ctypes.byref(ndim), shape), "bvc_videomae_param_info")
-        out.append((name.value.decode(), int(off.value), tuple(int(shape[j]) for j in range(ndim.value))))
-    return out, int(L.bvc_videomae_param_numel(ctypes.byref(cc)))
+    return query_layout(L.bvc_videomae_param_count, L.bvc_videomae_param_numel, L.bvc_videomae_param_info, config.to_c())
 
 
 class _Step(torch.autograd.Function):
@@ -103,85 +92,29 @@ class _Step(torch.autograd.Function):
         return None, None, None, None, None
 
 
-class VideoMAEForPreTraining(nn.Module):
+class VideoMAEForPreTraining(FlatParamModule):
     """Drop-in for transformers.VideoMAEForPreTraining on the pre-training path (same state-dict keys)."""
 
     def __init__(self, config: VideoMAEConfig):
         super().__init__()
         self.config = config
-        self._layout, self._numel = param_layout(config)
-        self._names = []
-        gen_std = config.initializer_range
-        for name, _off, shape in self._layout:
-            # transformers' _init_weights: normal(0, initializer_range) for Linear/Conv3d weights,
-            # zero biases, LayerNorm weight 1 / bias 0; mask_token is created as zeros (HF:515)
+        layout, numel = param_layout(config)
+        std = config.initializer_range
+
+        def init(name, shape):
+            # transformers' _init_weights: normal(0, initializer_range) for Linear/Conv3d weights, zero biases,
+            # LayerNorm weight 1 / bias 0; mask_token is created as zeros (HF:515)
             if len(shape) >= 2 and name != "mask_token":
-                t = torch.empty(shape).normal_(0.0, gen_std)
-            elif name.endswith("layernorm_before.weight") or name.endswith("layernorm_after.weight") or name == "decoder.norm.weight":
-                t = torch.ones(shape)
-            else:
-                t = torch.zeros(shape)
-            self._register(name, nn.Parameter(t))
-            self._names.append(name)
-        self._flat = None        # f32 flat parameter buffer (device); parameters are views into it
-        self._flat_grad = None   # f32 flat gradient buffer
+                return torch.empty(shape).normal_(0.0, std)
+            if name.endswith("layernorm_before.weight") or name.endswith("layernorm_after.weight") or name == "decoder.norm.weight":
+                return torch.ones(shape)
+            return torch.zeros(shape)
+
+        self._init_flat(layout, numel, init)
         self._ctx = None
         self._ctx_key = None
-        self._bucket_hook = None   # set by the data-parallel wrapper: fn(offset, count)
-        self._after_backward = None
         self.strict_mask_check = False
         self._nmask_cache = {}
-
-    # ---- parameters live under transformers' dotted names
-    def _register(self, dotted, param):
-        mod = self
-        parts = dotted.split(".")
-        for p in parts[:-1]:
-            if p not in mod._modules:
-                mod.add_module(p, nn.Module())
-            mod = mod._modules[p]
-        mod.register_parameter(parts[-1], param)
-
-    def _param(self, dotted):
-        mod = self
-        parts = dotted.split(".")
-        for p in parts[:-1]:
-            mod = mod._modules[p]
-        return mod._parameters[parts[-1]]
-
-    # ---- flat buffers
-    def _ensure_flat(self, device):
-        """Make every parameter a view into one contiguous f32 buffer in the library's layout.
-        Re-done whenever .to()/load_state_dict replaced parameter storage."""
-        flat = self._flat
-        ok = flat is not None and flat.device == device
-        if ok:
-            base = flat.data_ptr()
-            for name, off, _shape in self._layout:
-                if self._param(name).data_ptr() != base + 4 * off:
-                    ok = False
-                    break
-        if ok:
-            return
-        new = torch.empty(self._numel, dtype=torch.float32, device=device)
-        for name, off, shape in self._layout:
-            p = self._param(name)
-            n = p.numel()
-            new[off:off + n].copy_(p.data.reshape(-1).to(device=device, dtype=torch.float32))
-            p.data = new[off:off + n].view(shape)
-            p.grad = None
-        self._flat = new
-        self._flat_grad = None
-
-    def flat_parameters(self):
-        if self._flat is None:
-            raise RuntimeError("parameters are flattened on the first forward on a GPU (or call _ensure_flat(device))")
-        return self._flat
-
-    def flat_grads(self):
-        if self._flat_grad is None:
-            self._flat_grad = torch.zeros_like(self.flat_parameters())
-        return self._flat_grad
 
     # ---- library context
     def _get_ctx(self, batch, nmask):
@@ -234,30 +167,12 @@ class VideoMAEForPreTraining(nn.Module):
         return loss, logits
 
     def _run_backward(self, grad_loss):
-        G = self.flat_grads()
-        accumulate = any(self._param(n).grad is not None for n in (self._names[0], self._names[-1]))
-        target = torch.empty_like(G) if accumulate else G
+        target, accumulate = self._grad_target()
         g = grad_loss.detach().to(dtype=torch.float32).contiguous()
-        hook = self._bucket_hook if not accumulate else None
-        if hook is not None:
-            def _cb(offset, count, _user, _hook=hook):
-                _hook(int(offset), int(count))
-            cb = _lib.BUCKET_FN(_cb)
-        else:
-            cb = ctypes.cast(None, _lib.BUCKET_FN)
+        cb = self._bucket_callback(accumulate)
         _lib.check(_lib.lib().bvc_videomae_backward(self._ctx, g.data_ptr(), target.data_ptr(), cb, None,
                                                     _lib.current_stream_ptr()), "bvc_videomae_backward")
-        if accumulate:
-            G.add_(target)
-            if self._bucket_hook is not None:
-                self._bucket_hook(0, self._numel)
-        else:
-            for name, off, shape in self._layout:
-                p = self._param(name)
-                n = p.numel()
-                p.grad = G[off:off + n].view(shape)
-        if self._after_backward is not None:
-            self._after_backward()
+        self._publish_grads(target, accumulate)
         self._live = None
 
     def forward(self, pixel_values, bool_masked_pos=None, output_logits=False, **kwargs):

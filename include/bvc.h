@@ -93,6 +93,63 @@ int bvc_videomae_backward(bvc_ctx* ctx, const float* grad_loss_dev, float* grads
 int bvc_videomae_tap(bvc_ctx* ctx, const char* name, float* dst_dev, int64_t capacity, int64_t* numel, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * JEPA encoder and predictor (pretraining/predictive/vision_transformer.py).  Same conventions as above: flat f32
+ * parameter / gradient buffers whose entries carry the reference's state-dict keys (pos_embed, patch_embed.proj.*,
+ * blocks.N.{norm1,attn.qkv,attn.proj,norm2,mlp.fc1,mlp.fc2}.*, norm.* / mask_token, predictor_pos_embed,
+ * predictor_embed.*, predictor_blocks.N.*, predictor_norm.*, predictor_proj.*), borrowed device pointers, caller's stream.
+ * Token index lists are int32 (the reference's int64 masks are narrowed by the host shim).                          */
+typedef struct bvc_vit_config {
+    int image_size, patch_size, num_channels, num_frames, tubelet_size;
+    int embed_dim, depth, num_heads, mlp_hidden;
+    float eps; /* 1e-6: vit_base() etc. build LayerNorm with eps=1e-6 (vision_transformer.py:546-568) */
+} bvc_vit_config;
+typedef struct bvc_vit_ctx bvc_vit_ctx;
+int bvc_vit_param_count(const bvc_vit_config* cfg);
+int64_t bvc_vit_param_numel(const bvc_vit_config* cfg);
+int bvc_vit_param_info(const bvc_vit_config* cfg, int index, char* name, int name_cap, int64_t* offset, int64_t* numel,
+                       int* ndim, int64_t shape[5]);
+int bvc_vit_create(const bvc_vit_config* cfg, int max_batch, bvc_vit_ctx** out);
+void bvc_vit_destroy(bvc_vit_ctx* ctx);
+/* Replaces encoder(imgs, masks_enc) and target_encoder(imgs) (pretrain_jepa.py:386,395; VisionTransformer.forward,
+ * vision_transformer.py:378-402).  imgs f32 [B][T][C][H][W]; idx int32 [B][ntok] = tokens kept per sample, NULL = all;
+ * out f32 [B*ntok][embed_dim] (after the final LayerNorm). */
+int bvc_vit_forward(bvc_vit_ctx* ctx, const float* imgs_dev, const int* idx_dev, int batch, int ntok, const float* params_dev,
+                    float* out_dev, void* stream);
+/* d(out) f32 [B*ntok][embed_dim] -> flat gradients (overwritten); buckets reported tail-first as for VideoMAE. */
+int bvc_vit_backward(bvc_vit_ctx* ctx, const float* dout_dev, float* grads_dev, bvc_bucket_fn on_bucket, void* user, void* stream);
+
+typedef struct bvc_predictor_config {
+    int seq_len;    /* tokens of the full grid (num_patches of the encoder) */
+    int embed_dim;  /* encoder width */
+    int pred_dim;   /* predictor_embed_dim (384) */
+    int depth, num_heads, mlp_hidden;
+    float eps;
+} bvc_predictor_config;
+typedef struct bvc_pred_ctx bvc_pred_ctx;
+int bvc_predictor_param_count(const bvc_predictor_config* cfg);
+int64_t bvc_predictor_param_numel(const bvc_predictor_config* cfg);
+int bvc_predictor_param_info(const bvc_predictor_config* cfg, int index, char* name, int name_cap, int64_t* offset,
+                             int64_t* numel, int* ndim, int64_t shape[5]);
+int bvc_predictor_create(const bvc_predictor_config* cfg, int max_batch, int max_sets, int max_tokens, bvc_pred_ctx** out);
+void bvc_predictor_destroy(bvc_pred_ctx* ctx);
+/* Replaces predictor(z, masks_enc, masks_pred) (pretrain_jepa.py:396; VisionTransformerPredictor.forward,
+ * vision_transformer.py:494-535).  z f32 [B*Nc][embed_dim]; idx_ctx int32 [B][Nc]; idx_pred int32 [nsets][B][Np];
+ * out f32 [nsets*B*Np][embed_dim], rows ordered mask-set-major then sample, as apply_masks/cat produce them. */
+int bvc_predictor_forward(bvc_pred_ctx* ctx, const float* z_dev, const int* idx_ctx_dev, const int* idx_pred_dev, int B, int Nc,
+                          int nsets, int Np, const float* params_dev, float* out_dev, void* stream);
+int bvc_predictor_backward(bvc_pred_ctx* ctx, const float* dout_dev, float* grads_dev, float* dz_dev, void* stream);
+
+/* forward_target's post-processing (pretrain_jepa.py:387-392): F.layer_norm without affine over the feature dim, then the
+ * rows the prediction masks select: out[(i*B+b)*Np + j] = LN(h[b*L + idx_pred[i][b][j]]) */
+int bvc_op_target_select(const float* h, const int* idx_pred, float* out, int nsets, int B, int Np, int L, int D, float eps, void* stream);
+/* F.smooth_l1_loss(z, h), beta = 1, mean (pretrain_jepa.py:400); workspace = bvc_op_smooth_l1_workspace(n) floats */
+int bvc_op_smooth_l1_workspace(int64_t n);
+int bvc_op_smooth_l1_fwd(const float* z, const float* h, int64_t n, float* workspace, float* loss, void* stream);
+int bvc_op_smooth_l1_bwd(const float* z, const float* h, const float* grad_loss, int64_t n, float* dz, void* stream);
+/* target <- momentum * target + (1 - momentum) * online over a flat range (pretrain_jepa.py:431-432) */
+int bvc_op_ema(float* target, const float* online, int64_t n, float momentum, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Operator-level entry points (the kernels the step is built from; also used by the parity tests). */
 enum { BVC_GEMM_NT = 0, BVC_GEMM_NN = 1, BVC_GEMM_TN = 2 };
 enum {

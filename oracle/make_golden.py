@@ -168,11 +168,89 @@ def simclr_fixture():
     print("[simclr] reference info_nce_loss == oracle for", len(cases), "cases; B=8:", cases[0]["n_pos"], "pos /", cases[0]["n_neg"], "neg")
 
 
+def jepa_fixture():
+    """pretraining/predictive/{vision_transformer,tensors,mask}.py (need only torch/numpy): the reference's own encoder,
+    predictor and train-step arithmetic with the oracle's deterministic weights, and its MaskCollator under fixed seeds."""
+    import torch.nn.functional as F
+    from oracle import jepa_oracle as jo
+    sys.path.insert(0, os.path.join(REF, "pretraining", "predictive"))
+    for m in ("mask", "tensors", "vision_transformer"):
+        sys.modules.pop(m, None)
+    import vision_transformer as rvit
+    import tensors as rten
+    import mask as rmask
+    from functools import partial
+    cases = []
+    for name, cfg, B, n_ctx, n_pred, seed in [("tiny", jo.TINY, 3, 6, 4, 0), ("tiny_b", jo.TINY, 2, 9, 5, 1), ("vit_b", jo.VIT_B, 2, 83, 25, 0)]:
+        enc_p = jo.make_params(jo.encoder_shapes(cfg), cfg, seed)
+        pred_p = jo.make_params(jo.predictor_shapes(cfg), cfg, seed + 50)
+        tgt_p = jo.make_params(jo.encoder_shapes(cfg), cfg, seed + 100)
+        imgs, m_enc, m_pred = jo.synthetic_inputs(cfg, B, seed, n_ctx, n_pred)
+        kw = dict(img_size=[cfg.image_size], patch_size=cfg.patch_size, num_frames=cfg.num_frames, tubelet_size=cfg.tubelet_size,
+                  embed_dim=cfg.embed_dim, depth=cfg.depth, num_heads=cfg.num_heads, mlp_ratio=cfg.mlp_ratio, qkv_bias=True,
+                  norm_layer=partial(torch.nn.LayerNorm, eps=1e-6))
+        enc, tgt = rvit.VisionTransformer(**kw), rvit.VisionTransformer(**kw)
+        pred = rvit.vit_predictor(sequence_shape=enc.sequence_shape, embed_dim=cfg.embed_dim, predictor_embed_dim=cfg.pred_dim,
+                                  depth=cfg.pred_depth, num_heads=enc.num_heads)
+        assert set(enc.state_dict()) == set(enc_p) and set(pred.state_dict()) == set(pred_p)
+        # the reference's PositionalEncoding3D vs the oracle's restatement
+        assert torch.allclose(enc.pos_embed.data, enc_p["pos_embed"], atol=1e-6) and torch.allclose(pred.predictor_pos_embed.data, pred_p["predictor_pos_embed"], atol=1e-6)
+        enc.load_state_dict(enc_p); tgt.load_state_dict(tgt_p); pred.load_state_dict(pred_p)
+        with torch.no_grad():
+            h = tgt(imgs)
+            h = F.layer_norm(h, (h.size(-1),))
+            h = rten.apply_masks(h, m_pred)
+            h = rten.repeat_interleave_batch(h, B, repeat=len(m_enc))
+        zc = enc(imgs, m_enc)
+        z = pred(zc, m_enc, m_pred)
+        loss = F.smooth_l1_loss(z, h)
+        loss.backward()
+        oloss, oge, ogp, oz, oh = jo.step(cfg, enc_p, pred_p, tgt_p, imgs, m_enc, m_pred)
+        assert abs(float(oloss) - float(loss)) / float(loss) < 2e-6, (name, float(oloss), float(loss))
+        assert float((oz - z.detach()).norm() / z.detach().norm()) < 2e-5 and float((oh - h).norm() / h.norm()) < 2e-5
+        worst = 0.0
+        gmax = max(float(p.grad.norm()) for p in list(enc.parameters()) + list(pred.parameters()) if p.grad is not None)
+        for mod, og in ((enc, oge), (pred, ogp)):
+            for k, p in mod.named_parameters():
+                if p.grad is None:
+                    continue
+                e = float((og[k] - p.grad).norm() / (p.grad.norm() + 1e-4 * gmax))
+                worst = max(worst, e)
+                assert e < 5e-5, (name, k, e)
+        print(f"[jepa {name}] oracle vs reference modules: loss rel {abs(float(oloss)-float(loss))/float(loss):.1e}, worst grad rel {worst:.1e}")
+        first_qkv = "blocks.0.attn.qkv.weight"
+        last_qkv = f"blocks.{cfg.depth - 1}.attn.qkv.weight"
+        gn = dict(enc.named_parameters())
+        cases.append({"case": name, "config": cfg.__dict__, "B": B, "n_ctx": n_ctx, "n_pred": n_pred, "seed": seed,
+                      "loss": float(loss), "z": summarize(z), "h": summarize(h), "zc": summarize(zc),
+                      "grad_first_qkv": float(gn[first_qkv].grad.double().norm()), "grad_last_qkv": float(gn[last_qkv].grad.double().norm()),
+                      "enc_grad_l2": {k: float(p.grad.double().norm()) for k, p in enc.named_parameters() if p.grad is not None},
+                      "pred_grad_l2": {k: float(p.grad.double().norm()) for k, p in pred.named_parameters() if p.grad is not None}})
+    # MaskCollator: block sizes are seeded by the step counter, positions by the global torch RNG
+    mc_cases = []
+    for gseed in (0, 5):
+        torch.manual_seed(gseed)
+        mc = rmask.MaskCollator(input_size=224, patch_size=16, pred_mask_scale=(0.15, 0.2), enc_mask_scale=(0.85, 1.0),
+                                aspect_ratio=(0.75, 1.5), nenc=1, npred=4, allow_overlap=False, min_keep=10)
+        batch = [torch.zeros(1) for _ in range(4)]
+        outs = []
+        for _ in range(2):
+            _, me, mp = mc(batch)
+            outs.append({"enc_shape": list(me[0].shape), "pred_shape": list(mp[0].shape), "enc_row0": [int(v) for v in me[0][0]],
+                         "pred0_row0": [int(v) for v in mp[0][0]], "pred3_row3": [int(v) for v in mp[3][3]]})
+        upd = rmask.update_masks([torch.arange(5).view(1, 5)], 224, 16, 2, 1, isencoder=False)
+        mc_cases.append({"torch_seed": gseed, "steps": outs, "update_masks_offset": int(upd[0][0, 0])})
+    with open(os.path.join(GOLD, "jepa.json"), "w") as f:
+        json.dump({"source": "pretraining/predictive/vision_transformer.py, tensors.py, mask.py, pretrain_jepa.py:383-402",
+                   "cases": cases, "mask_collator": mc_cases}, f, indent=1)
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     torch.manual_seed(0)
     mask_fixture()
     simclr_fixture()
+    jepa_fixture()
     if "--only-new" in sys.argv:
         return
     one_case("tiny_s0", vo.TINY, batch=2, seed=0, mask_ratio=0.75)

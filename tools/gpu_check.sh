@@ -33,6 +33,8 @@ for step in "$@"; do
     benchov) BVC_DW_OVERLAP=1 run benchov 300 python bench.py --no-cpu-baseline ;;
     micro) run micro 400 python tools/microbench.py ;;
     probe) run probe 300 python tools/gemm_probe.py ;;
+    jepa) run jepa 400 python tools/bench_jepa.py ;;
+    simclr) run simclr 400 python tools/bench_simclr.py ;;
     prof)  rm -rf $OUT/prof; cd /tmp
            run prof 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline
            cd $R

@@ -87,10 +87,7 @@ __device__ __forceinline__ bf16x8 read_frag(const char* lds, int rbase, int ks, 
         const char* a1 = lds + k1 * (BR * 2) + ((chunk ^ swz_tr<BR>(k1)) << 4) + within;
         bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)(a0));
         bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)(a1));
-        bf16x8 r;
-        r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
-        r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
-        return r;
+        return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
     }
 }
 
@@ -98,11 +95,10 @@ template <int N>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // ------------------------------------------------------------------ the kernel
-// NS = LDS ring depth.  NS-1 K-steps of LDS-DMA are in flight while one is being multiplied; the
-// loop waits with a COUNTED vmcnt (never 0 except at the tail) and a raw s_barrier, so the DMA of
-// later stages keeps flying across the barrier (a __syncthreads() would drain it).
+// Two LDS slots; waits use a COUNTED vmcnt and raw s_barrier so that the refill DMA keeps flying across barriers
+// (a __syncthreads() would drain it).  NS is kept as a template parameter for the launcher's LDS sizing only (= 2).
 template <int BM, int BN, bool AT, bool BT, int NS>
-__global__ __launch_bounds__(256) void gemm_kernel(const GemmGroup g) {
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmGroup g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int BK = 64;
     constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
@@ -154,53 +150,58 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmGroup g) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) ones[e] = (short)0x3F80;
 
-#pragma unroll
-    for (int s = 0; s < NS - 1; ++s) {
-        if (s < nt) {
-            stage_tile<BM, AT>(ra, m0, (t0 + s) * BK, p.lda, smem + s * STAGE, wave, lane);
-            stage_tile<BN, BT>(rb, n0, (t0 + s) * BK, p.ldb, smem + s * STAGE + A_BYTES, wave, lane);
+    // K loop, "early refill": every wave first pulls ALL its fragments of the current K-step into registers, a barrier
+    // proves the slot is drained, the slot is refilled by LDS-DMA at once (K-step t+2) and only then do the MFMAs run -
+    // from registers.  Two K-steps of DMA are in flight during the MFMAs with just two 32 KiB slots (the plain double
+    // buffer had one, and rocprofv3 showed ~50 % of wave cycles waiting on it), so 2 workgroups still fit per CU.
+    if (nt > 0) {
+        stage_tile<BM, AT>(ra, m0, t0 * BK, p.lda, smem, wave, lane);
+        stage_tile<BN, BT>(rb, n0, t0 * BK, p.ldb, smem + A_BYTES, wave, lane);
+        if (nt > 1) {
+            stage_tile<BM, AT>(ra, m0, (t0 + 1) * BK, p.lda, smem + STAGE, wave, lane);
+            stage_tile<BN, BT>(rb, n0, (t0 + 1) * BK, p.ldb, smem + STAGE + A_BYTES, wave, lane);
+            wait_vmcnt<DMA_PER_STAGE>();
+        } else {
+            wait_vmcnt<0>();
         }
+        asm volatile("s_barrier" ::: "memory");
     }
-    int slot = 0, fill = NS - 1;   // slot being multiplied / slot the next DMA goes to
     for (int it = 0; it < nt; ++it) {
-        // Stage `it` must have landed: all but the youngest min(NS-2, remaining) stages' DMAs are done.
-        const int rem = nt - 1 - it;
-        if (NS >= 4 && rem >= 2) wait_vmcnt<2 * DMA_PER_STAGE>();
-        else if (NS >= 3 && rem >= 1) wait_vmcnt<DMA_PER_STAGE>();
-        else wait_vmcnt<0>();
-        // own LDS reads of the previous step retired, then the barrier: publishes stage `it` from every
-        // wave and proves every wave is done reading the slot that is refilled next
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        if (it + NS - 1 < nt) {
-            char* nxt = smem + fill * STAGE;
-            stage_tile<BM, AT>(ra, m0, (t0 + it + NS - 1) * BK, p.lda, nxt, wave, lane);
-            stage_tile<BN, BT>(rb, n0, (t0 + it + NS - 1) * BK, p.ldb, nxt + A_BYTES, wave, lane);
-        }
-        const char* la = smem + slot * STAGE;
-        const char* lb = la + A_BYTES;
+        char* slot = smem + (it & 1) * STAGE;
+        bf16x8 af[2][TM], bfr[2][TN];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 af[TM], bfr[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = read_frag<BM, AT>(la, wm * WM + 16 * i, ks, lane);
+            for (int i = 0; i < TM; ++i) af[ks][i] = read_frag<BM, AT>(slot, wm * WM + 16 * i, ks, lane);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bfr[j] = read_frag<BN, BT>(lb, wn * WN + 16 * j, ks, lane);
+            for (int j = 0; j < TN; ++j) bfr[ks][j] = read_frag<BN, BT>(slot + A_BYTES, wn * WN + 16 * j, ks, lane);
+        }
+        if (it + 2 < nt) {
+            // own fragment reads retired, then the barrier: every wave is done with this slot -> refill it
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            stage_tile<BM, AT>(ra, m0, (t0 + it + 2) * BK, p.lda, slot, wave, lane);
+            stage_tile<BN, BT>(rb, n0, (t0 + it + 2) * BK, p.ldb, slot + A_BYTES, wave, lane);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     // operands swapped: D = Bfrag^T-view x Afrag gives lane (l&15) = m, regs = 4 consecutive n
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ks][j], af[ks][i], acc[i][j], 0, 0, 0);
             if (do_rowsum) {
 #pragma unroll
-                for (int i = 0; i < TM; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[i], accb[i], 0, 0, 0);
+                for (int i = 0; i < TM; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[ks][i], accb[i], 0, 0, 0);
             }
         }
-        slot = slot + 1 == NS ? 0 : slot + 1;
-        fill = fill + 1 == NS ? 0 : fill + 1;
+        if (it + 1 < nt) {
+            // K-step it+1 must have landed everywhere before the next iteration reads it; the refill just issued may fly on
+            if (it + 2 < nt) wait_vmcnt<DMA_PER_STAGE>(); else wait_vmcnt<0>();
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
     }
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // LDS is reused by the loss epilogue
-
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // LDS is reused by the epilogue
     // ------------------------------------------------------------------ epilogue
     // The MFMA fragment layout gives each lane 4 columns of one row: stored directly, a wave touches 16 rows x 32 B
     // per instruction and the write path reaches only ~2.2 TB/s (measured).  Instead every wave parks its f32 tile in
@@ -438,21 +439,13 @@ static int launch_cfg(const GemmGroup& g, GemmLayout layout, int nblocks, hipStr
 }
 
 template <int BM, int BN>
-static int launch_stages(const GemmGroup& g, GemmLayout layout, int stages, int nblocks, hipStream_t stream) {
-    switch (stages) {
-        case 2: return launch_cfg<BM, BN, 2>(g, layout, nblocks, stream);
-        case 3: return launch_cfg<BM, BN, 3>(g, layout, nblocks, stream);
-        default: return launch_cfg<BM, BN, 4>(g, layout, nblocks, stream);
-    }
+static int launch_stages(const GemmGroup& g, GemmLayout layout, int /*stages*/, int nblocks, hipStream_t stream) {
+    return launch_cfg<BM, BN, 2>(g, layout, nblocks, stream);
 }
 
-// ring depth.  Measured: a third stage only pays for long-K k-contiguous products on the small tile
-// (enc fc2, K = 3072: 27 -> 23 us); everywhere else it costs a resident workgroup per CU and loses.
-int gemm_pick_stages(int cfg, GemmLayout layout, int kmax, int stages) {
-    if (stages >= 2 && stages <= 4) return stages;
-    if (layout == GEMM_NT && cfg == 2 && kmax >= 2048) return 3;
-    return 2;
-}
+// The K loop keeps two K-steps of LDS-DMA in flight out of two LDS slots (see gemm_kernel); deeper rings were measured
+// slower (they cost the second resident workgroup per CU), so `stages` is accepted for API stability and ignored.
+int gemm_pick_stages(int, GemmLayout, int, int) { return 2; }
 
 int launch_gemm(const GemmProblem* probs, int nprob, GemmLayout layout, int tile_cfg, hipStream_t stream, int stages) {
     BVC_REQUIRE(nprob >= 1 && nprob <= kMaxGroup, "launch_gemm: nprob %d out of range", nprob);

@@ -150,55 +150,96 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmGroup g) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) ones[e] = (short)0x3F80;
 
-    // K loop, "early refill": every wave first pulls ALL its fragments of the current K-step into registers, a barrier
-    // proves the slot is drained, the slot is refilled by LDS-DMA at once (K-step t+2) and only then do the MFMAs run -
-    // from registers.  Two K-steps of DMA are in flight during the MFMAs with just two 32 KiB slots (the plain double
-    // buffer had one, and rocprofv3 showed ~50 % of wave cycles waiting on it), so 2 workgroups still fit per CU.
-    if (nt > 0) {
-        stage_tile<BM, AT>(ra, m0, t0 * BK, p.lda, smem, wave, lane);
-        stage_tile<BN, BT>(rb, n0, t0 * BK, p.ldb, smem + A_BYTES, wave, lane);
-        if (nt > 1) {
-            stage_tile<BM, AT>(ra, m0, (t0 + 1) * BK, p.lda, smem + STAGE, wave, lane);
-            stage_tile<BN, BT>(rb, n0, (t0 + 1) * BK, p.ldb, smem + STAGE + A_BYTES, wave, lane);
-            wait_vmcnt<DMA_PER_STAGE>();
-        } else {
+    // Weight-gradient products (both operands read through ds_read_b64_tr_b16, 64 reads per K-step) measured FASTER with the
+    // plain double buffer, where hipcc interleaves reads and MFMAs (dec dW group 189 vs 236 us); everything else uses the
+    // early-refill loop below.
+    constexpr bool EARLY = !(AT && BT);
+    if constexpr (!EARLY) {
+        if (nt > 0) {
+            stage_tile<BM, AT>(ra, m0, t0 * BK, p.lda, smem, wave, lane);
+            stage_tile<BN, BT>(rb, n0, t0 * BK, p.ldb, smem + A_BYTES, wave, lane);
+        }
+        for (int it = 0; it < nt; ++it) {
+            // every wave drains its own DMA, then the barrier publishes the tile and proves the other slot is drained
             wait_vmcnt<0>();
-        }
-        asm volatile("s_barrier" ::: "memory");
-    }
-    for (int it = 0; it < nt; ++it) {
-        char* slot = smem + (it & 1) * STAGE;
-        bf16x8 af[2][TM], bfr[2][TN];
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-            for (int i = 0; i < TM; ++i) af[ks][i] = read_frag<BM, AT>(slot, wm * WM + 16 * i, ks, lane);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) bfr[ks][j] = read_frag<BN, BT>(slot + A_BYTES, wn * WN + 16 * j, ks, lane);
-        }
-        if (it + 2 < nt) {
-            // own fragment reads retired, then the barrier: every wave is done with this slot -> refill it
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            stage_tile<BM, AT>(ra, m0, (t0 + it + 2) * BK, p.lda, slot, wave, lane);
-            stage_tile<BN, BT>(rb, n0, (t0 + it + 2) * BK, p.ldb, slot + A_BYTES, wave, lane);
-        }
+            if (it + 1 < nt) {
+                char* nxt = smem + ((it + 1) & 1) * STAGE;
+                stage_tile<BM, AT>(ra, m0, (t0 + it + 1) * BK, p.lda, nxt, wave, lane);
+                stage_tile<BN, BT>(rb, n0, (t0 + it + 1) * BK, p.ldb, nxt + A_BYTES, wave, lane);
+            }
+            const char* la = smem + (it & 1) * STAGE;
+            const char* lb = la + A_BYTES;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 af[TM], bfr[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+                for (int i = 0; i < TM; ++i) af[i] = read_frag<BM, AT>(la, wm * WM + 16 * i, ks, lane);
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    // operands swapped: D = Bfrag^T-view x Afrag gives lane (l&15) = m, regs = 4 consecutive n
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ks][j], af[ks][i], acc[i][j], 0, 0, 0);
-            if (do_rowsum) {
+                for (int j = 0; j < TN; ++j) bfr[j] = read_frag<BN, BT>(lb, wn * WN + 16 * j, ks, lane);
 #pragma unroll
-                for (int i = 0; i < TM; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[ks][i], accb[i], 0, 0, 0);
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+                if (do_rowsum) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[i], accb[i], 0, 0, 0);
+                }
             }
         }
-        if (it + 1 < nt) {
-            // K-step it+1 must have landed everywhere before the next iteration reads it; the refill just issued may fly on
-            if (it + 2 < nt) wait_vmcnt<DMA_PER_STAGE>(); else wait_vmcnt<0>();
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    } else {
+        // K loop, "early refill": every wave first pulls ALL its fragments of the current K-step into registers, a barrier
+        // proves the slot is drained, the slot is refilled by LDS-DMA at once (K-step t+2) and only then do the MFMAs run -
+        // from registers.  Two K-steps of DMA are in flight during the MFMAs with just two 32 KiB slots (the plain double
+        // buffer had one, and rocprofv3 showed ~50 % of wave cycles waiting on it), so 2 workgroups still fit per CU.
+        if (nt > 0) {
+            stage_tile<BM, AT>(ra, m0, t0 * BK, p.lda, smem, wave, lane);
+            stage_tile<BN, BT>(rb, n0, t0 * BK, p.ldb, smem + A_BYTES, wave, lane);
+            if (nt > 1) {
+                stage_tile<BM, AT>(ra, m0, (t0 + 1) * BK, p.lda, smem + STAGE, wave, lane);
+                stage_tile<BN, BT>(rb, n0, (t0 + 1) * BK, p.ldb, smem + STAGE + A_BYTES, wave, lane);
+                wait_vmcnt<DMA_PER_STAGE>();
+            } else {
+                wait_vmcnt<0>();
+            }
+            asm volatile("s_barrier" ::: "memory");
+        }
+        for (int it = 0; it < nt; ++it) {
+            char* slot = smem + (it & 1) * STAGE;
+            bf16x8 af[2][TM], bfr[2][TN];
+    #pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+    #pragma unroll
+                for (int i = 0; i < TM; ++i) af[ks][i] = read_frag<BM, AT>(slot, wm * WM + 16 * i, ks, lane);
+    #pragma unroll
+                for (int j = 0; j < TN; ++j) bfr[ks][j] = read_frag<BN, BT>(slot + A_BYTES, wn * WN + 16 * j, ks, lane);
+            }
+            auto mfma_half = [&](int ks) {
+    #pragma unroll
+                for (int i = 0; i < TM; ++i)
+    #pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        // operands swapped: D = Bfrag^T-view x Afrag gives lane (l&15) = m, regs = 4 consecutive n
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ks][j], af[ks][i], acc[i][j], 0, 0, 0);
+                if (do_rowsum) {
+    #pragma unroll
+                    for (int i = 0; i < TM; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[ks][i], accb[i], 0, 0, 0);
+                }
+            };
+            mfma_half(0);   // needs only the first half's fragments: the second half's LDS reads retire underneath
+            if (it + 2 < nt) {
+                // own fragment reads retired, then the barrier: every wave is done with this slot -> refill it
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                stage_tile<BM, AT>(ra, m0, (t0 + it + 2) * BK, p.lda, slot, wave, lane);
+                stage_tile<BN, BT>(rb, n0, (t0 + it + 2) * BK, p.ldb, slot + A_BYTES, wave, lane);
+            }
+            mfma_half(1);
+            if (it + 1 < nt) {
+                // K-step it+1 must have landed everywhere before the next iteration reads it; the refill just issued may fly on
+                if (it + 2 < nt) wait_vmcnt<DMA_PER_STAGE>(); else wait_vmcnt<0>();
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            }
         }
     }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // LDS is reused by the epilogue
@@ -222,7 +263,25 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmGroup g) {
             *reinterpret_cast<AS3 f32x4*>(wl + row * (WN * 4) + unit * 16) = acc[i][j];
         }
     }
-    if (nt > 0 || !atomic) {
+    if (atomic) {
+        // split-K: f32 atomics straight into C.  Float atomics run at full rate only when a wave-instruction covers whole
+        // contiguous rows (256 B = one row of a 64-wide wave tile, or two 128-B rows of a 32-wide one), so the lanes walk
+        // the parked tile one dword each, row by row, instead of the 8-column chunks of the store path.
+        if (nt > 0) {
+            float* cbase = reinterpret_cast<float*>(p.C);
+#pragma unroll 4
+            for (int idx = lane; idx < WM * WN; idx += 64) {
+                const int row = idx / WN, col = idx % WN;
+                const int m = m0 + wm * WM + row, n = n0 + wn * WN + col;
+                const int unit = (col >> 2) ^ (row & (UNITS - 1));
+                float v = *reinterpret_cast<const AS3 float*>(wl + row * (WN * 4) + unit * 16 + (col & 3) * 4) * alpha;
+                if (m < p.M && n < p.N) {
+                    if (p.bias && split == 0) v += p.bias[n];
+                    atomicAdd(cbase + (size_t)m * p.ldc + n, v);
+                }
+            }
+        }
+    } else if (nt > 0 || !atomic) {
         constexpr int CPR = WN / 8;                     // 8-column chunks per row
         constexpr int NCH = WM * WN / 8 / 64;           // chunks per lane
 #pragma unroll 2

@@ -97,8 +97,8 @@ __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)
 // ------------------------------------------------------------------ the kernel
 // Two LDS slots; waits use a COUNTED vmcnt and raw s_barrier so that the refill DMA keeps flying across barriers
 // (a __syncthreads() would drain it).  NS is kept as a template parameter for the launcher's LDS sizing only (= 2).
-template <int BM, int BN, bool AT, bool BT, int NS>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmGroup g) {
+template <int BM, int BN, bool AT, bool BT, int NS, int LB = 2, bool EARLY_ = true>
+__global__ __launch_bounds__(256, LB) void gemm_kernel(const GemmGroup g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int BK = 64;
     constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
@@ -150,10 +150,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmGroup g) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) ones[e] = (short)0x3F80;
 
-    // Weight-gradient products (both operands read through ds_read_b64_tr_b16, 64 reads per K-step) measured FASTER with the
-    // plain double buffer, where hipcc interleaves reads and MFMAs (dec dW group 189 vs 236 us); everything else uses the
-    // early-refill loop below.
-    constexpr bool EARLY = !(AT && BT);
+    // Two K-loop variants, A/B'd in ONE run on one box (profiles/r01_d_kloop_ab.txt; box-to-box variance on the pool is far
+    // larger than the effect): the early-refill loop below wins for NN (5-15 %) and TN (~8 %), ties for NT at K <= 768 and wins
+    // at long K (enc fc2 22 vs 27 us).  The plain double buffer is kept reachable (stages = 4) for such comparisons.
+    constexpr bool EARLY = EARLY_;
     if constexpr (!EARLY) {
         if (nt > 0) {
             stage_tile<BM, AT>(ra, m0, t0 * BK, p.lda, smem, wave, lane);
@@ -473,16 +473,16 @@ int gemm_pick_tile(const GemmProblem* probs, int nprob, int tile_cfg) {
 
 int gemm_num_tiles(const GemmProblem& p, int tile_cfg) { return tiles_for(p, gemm_pick_tile(&p, 1, tile_cfg)); }
 
-template <int BM, int BN, bool AT, bool BT, int NS>
+template <int BM, int BN, bool AT, bool BT, int NS, int LB = 2, bool EARLY = true>
 static int launch_one(const GemmGroup& g, int nblocks, hipStream_t stream) {
     constexpr size_t lds = (size_t)NS * (BM + BN) * 64 * 2;
     static bool attr_set = false;   // > 64 KiB of dynamic LDS needs the attribute once per kernel
     if (lds > 65536 && !attr_set) {
-        BVC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<BM, BN, AT, BT, NS>),
+        BVC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<BM, BN, AT, BT, NS, LB, EARLY>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, AT, BT, NS>), dim3(nblocks), dim3(256), lds, stream, g);
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, AT, BT, NS, LB, EARLY>), dim3(nblocks), dim3(256), lds, stream, g);
     BVC_CHECK_HIP(hipGetLastError());
     return BVC_OK;
 }
@@ -498,13 +498,21 @@ static int launch_cfg(const GemmGroup& g, GemmLayout layout, int nblocks, hipStr
 }
 
 template <int BM, int BN>
-static int launch_stages(const GemmGroup& g, GemmLayout layout, int /*stages*/, int nblocks, hipStream_t stream) {
+static int launch_stages(const GemmGroup& g, GemmLayout layout, int stages, int nblocks, hipStream_t stream) {
+    // experiment hooks (same-run A/B; box-to-box variance on the pool is +-40 %): stages 3 = AGPR-form MFMA for TN (measured
+    // 5-25 % slower), stages 4 = the other K-loop variant for the layout
+    if (stages == 3 && layout == GEMM_TN) return launch_one<BM, BN, true, true, 2, 1>(g, nblocks, stream);
+    if (stages == 4) {
+        if (layout == GEMM_NT) return launch_one<BM, BN, false, false, 2, 2, false>(g, nblocks, stream);
+        if (layout == GEMM_NN) return launch_one<BM, BN, false, true, 2, 2, false>(g, nblocks, stream);
+        return launch_one<BM, BN, true, true, 2, 2, false>(g, nblocks, stream);
+    }
     return launch_cfg<BM, BN, 2>(g, layout, nblocks, stream);
 }
 
 // The K loop keeps two K-steps of LDS-DMA in flight out of two LDS slots (see gemm_kernel); deeper rings were measured
 // slower (they cost the second resident workgroup per CU), so `stages` is accepted for API stability and ignored.
-int gemm_pick_stages(int, GemmLayout, int, int) { return 2; }
+int gemm_pick_stages(int, GemmLayout, int, int stages) { return (stages == 3 || stages == 4) ? stages : 2; }
 
 int launch_gemm(const GemmProblem* probs, int nprob, GemmLayout layout, int tile_cfg, hipStream_t stream, int stages) {
     BVC_REQUIRE(nprob >= 1 && nprob <= kMaxGroup, "launch_gemm: nprob %d out of range", nprob);

@@ -10,7 +10,8 @@ Host-side mirror of the model interface the reference's entry points use
 memory, streams, the optimiser object and torch.distributed only.
 """
 from . import _lib  # noqa: F401
-from .videomae import VideoMAEConfig, VideoMAEForPreTraining, VideoMAEForPreTrainingOutput, get_config, get_model  # noqa: F401
+from .videomae import (VideoMAEConfig, VideoMAEForPreTraining, VideoMAEForPreTrainingOutput, VideoMAEForVideoClassification,  # noqa: F401
+                       get_config, get_model)
 from .mask import TubeMaskingGenerator, RandomMaskingGenerator  # noqa: F401
 from .ddp import DistributedDataParallel  # noqa: F401
 from .ddputils import AllReduce  # noqa: F401

@@ -64,6 +64,10 @@ SYMBOLS = {
     "bvc_videomae_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "bvc_videomae_backward": (c_int, [c_void_p, c_void_p, c_void_p, BUCKET_FN, c_void_p, c_void_p]),
     "bvc_videomae_tap": (c_int, [c_void_p, c_char_p, c_void_p, c_int64, ctypes.POINTER(c_int64), c_void_p]),
+    "bvc_videomae_encoder_param_numel": (c_int64, [ctypes.POINTER(VideoMAEConfigC)]),
+    "bvc_videomae_encoder_create": (c_int, [ctypes.POINTER(VideoMAEConfigC), c_int, ctypes.POINTER(c_void_p)]),
+    "bvc_videomae_encoder_destroy": (None, [c_void_p]),
+    "bvc_videomae_encode": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p]),
     "bvc_vit_param_count": (c_int, [ctypes.POINTER(VitConfigC)]),
     "bvc_vit_param_numel": (c_int64, [ctypes.POINTER(VitConfigC)]),
     "bvc_vit_param_info": (c_int, [ctypes.POINTER(VitConfigC), c_int, ctypes.c_char_p, c_int, ctypes.POINTER(c_int64),

@@ -30,6 +30,8 @@
 // K/V (or Q/dO) tiles of 64 rows x 64 bf16 go HBM -> LDS by LDS-DMA into a 2-stage ring, XOR-swizzled
 // so that both the ds_read_b128 row reads and the transposed reads of the same image are
 // bank-conflict free (SQ_LDS_BANK_CONFLICT = 0 measured).
+#include <stdlib.h>
+
 #include "attention.h"
 
 namespace bvc {
@@ -193,19 +195,36 @@ __device__ __forceinline__ void fwd_subtile(const AS3 char* lds, const FragAddr<
     for (int t = 0; t < HD / 32; ++t) st.o[t] = MFMA32(lds_tr<VOFF + KS>(lds, fa.tr[t][0], fa.tr[t][1]), p1, st.o[t]);
 }
 
-// grid (ceil(N/128), B*H); 256 threads; wave w owns queries q0 + 32 w .. + 31
+// Block -> (tile, clip-head) map.  Workgroups are dealt round-robin to the 8 XCDs (block b and b+8 share an L2), so XCD x is
+// given a contiguous run of logical ids: the tiles of one (clip, head), which all stream the same K/V (or Q/dO) rows, then
+// meet in ONE L2 instead of eight.  Measured (profiles/r01_d_traffic_b16.json): with the plain (tile, head) grid the forward
+// fetched 1.59 GB per step through the fabric against 0.37 GB of qkv.  remap = 0 keeps the plain order (A/B only).
+__device__ __forceinline__ void attn_block(int tiles, int remap, int& tile, int& bh) {
+    const int nb = gridDim.x, bid = blockIdx.x;
+    int lid = bid;
+    if (remap) {
+        const int xq = nb >> 3, xr = nb & 7, xcd = bid & 7;
+        lid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
+    }
+    bh = lid / tiles;
+    tile = lid - bh * tiles;
+}
+
+// grid ceil(N/128) * B*H (1-D, see attn_block); 256 threads; wave w owns queries q0 + 32 w .. + 31
 template <int HD>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx,
                                                           float* __restrict__ lse, int N, int H, int D,
-                                                          uint32_t qkv_bytes, float scale_log2) {
+                                                          uint32_t qkv_bytes, float scale_log2, int remap) {
     extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 stages x (K image + V image)
     constexpr int IMG = 64 * HD * 2, STG = 2 * IMG, SUB = 32 * HD * 2;
     const AS3 char* lds = (const AS3 char*)smem;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int bh = blockIdx.y, b = bh / H, head = bh % H;
+    int tile_, bh;
+    attn_block((N + 127) >> 7, remap, tile_, bh);
+    const int b = bh / H, head = bh % H;
     const int ld = 3 * D;
-    const int qi = blockIdx.x * 128 + wave * 32 + (lane & 31);   // this lane's query
+    const int qi = tile_ * 128 + wave * 32 + (lane & 31);   // this lane's query
     const int h = lane >> 5;
     const __amdgpu_buffer_rsrc_t rs = make_rsrc(qkv, qkv_bytes);
     const FragAddr<HD> fa = make_frag_addr<HD>(lane);
@@ -319,15 +338,17 @@ template <int HD>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dctx,
                                                              const float* __restrict__ lse, const float* __restrict__ delta,
                                                              bf16_t* __restrict__ dqkv, int N, int H, int D,
-                                                             uint32_t qkv_bytes, float scale, float scale_log2) {
+                                                             uint32_t qkv_bytes, float scale, float scale_log2, int remap) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int IMG = 64 * HD * 2, STG = 2 * IMG, SUB = 32 * HD * 2;
     const AS3 char* lds = (const AS3 char*)smem;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int bh = blockIdx.y, b = bh / H, head = bh % H;
+    int tile_, bh;
+    attn_block((N + 127) >> 7, remap, tile_, bh);
+    const int b = bh / H, head = bh % H;
     const int ld = 3 * D;
-    const int qi = blockIdx.x * 128 + wave * 32 + (lane & 31);
+    const int qi = tile_ * 128 + wave * 32 + (lane & 31);
     const int qc = min(qi, N - 1);
     const int h = lane >> 5;
     const __amdgpu_buffer_rsrc_t rs = make_rsrc(qkv, qkv_bytes);
@@ -434,15 +455,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const bf16_t* __r
                                                                const float* __restrict__ lse, const float* __restrict__ delta,
                                                                bf16_t* __restrict__ dqkv, int N, int H, int D,
                                                                uint32_t qkv_bytes, uint32_t dctx_bytes, uint32_t stat_bytes,
-                                                               float scale, float scale_log2) {
+                                                               float scale, float scale_log2, int remap) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int IMG = 64 * HD * 2, SUB = 32 * HD * 2, STG = 2 * IMG + 512;
     const AS3 char* lds = (const AS3 char*)smem;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int bh = blockIdx.y, b = bh / H, head = bh % H;
+    int tile_, bh;
+    attn_block((N + 127) >> 7, remap, tile_, bh);
+    const int b = bh / H, head = bh % H;
     const int ld = 3 * D;
-    const int ki = blockIdx.x * 128 + wave * 32 + (lane & 31);   // this lane's key
+    const int ki = tile_ * 128 + wave * 32 + (lane & 31);   // this lane's key
     const int kc = min(ki, N - 1);
     const int h = lane >> 5;
     const __amdgpu_buffer_rsrc_t rq = make_rsrc(qkv, qkv_bytes);
@@ -503,13 +526,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const bf16_t* __r
 }
 
 // ============================================================================ host launchers
+// BVC_ATTN_PLAIN_GRID=1 switches the XCD-aware block map off (same-run A/B in tools/microbench.py; read per launch)
+static int xcd_remap() { return getenv("BVC_ATTN_PLAIN_GRID") == nullptr; }
+
 template <int HD>
 static int fwd_hd(const bf16_t* qkv, bf16_t* ctx, float* lse, int B, int N, int H, hipStream_t stream) {
     const int D = H * HD;
     const size_t bytes = (size_t)B * N * 3 * D * 2;
     const float scale_log2 = (1.0f / sqrtf((float)HD)) * 1.4426950408889634f;
-    dim3 grid((N + 127) / 128, B * H);
-    hipLaunchKernelGGL(attn_fwd_kernel<HD>, grid, dim3(256), 4 * 64 * HD * 2, stream, qkv, ctx, lse, N, H, D, (uint32_t)bytes, scale_log2);
+    const dim3 grid((unsigned)(((N + 127) / 128) * B * H));
+    hipLaunchKernelGGL(attn_fwd_kernel<HD>, grid, dim3(256), 4 * 64 * HD * 2, stream, qkv, ctx, lse, N, H, D, (uint32_t)bytes, scale_log2,
+                       xcd_remap());
     BVC_CHECK_HIP(hipGetLastError());
     return BVC_OK;
 }
@@ -524,11 +551,12 @@ static int bwd_hd(const bf16_t* qkv, const bf16_t* ctx, const bf16_t* dctx, cons
         const long long total = (long long)B * N * H * (HD / 8);
         hipLaunchKernelGGL(attn_delta_kernel<HD>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, dctx, ctx, delta, B, N, H, D);
     }
-    dim3 grid((N + 127) / 128, B * H);
+    const dim3 grid((unsigned)(((N + 127) / 128) * B * H));
+    const int remap = xcd_remap();
     hipLaunchKernelGGL(attn_bwd_dkdv_kernel<HD>, grid, dim3(256), 2 * (2 * 64 * HD * 2 + 512), stream, qkv, dctx, lse, delta, dqkv, N, H, D,
-                       (uint32_t)bytes, (uint32_t)((size_t)B * N * D * 2), (uint32_t)((size_t)B * H * N * 4), scale, scale_log2);
+                       (uint32_t)bytes, (uint32_t)((size_t)B * N * D * 2), (uint32_t)((size_t)B * H * N * 4), scale, scale_log2, remap);
     hipLaunchKernelGGL(attn_bwd_dq_kernel<HD>, grid, dim3(256), 4 * 64 * HD * 2, stream, qkv, dctx, lse, delta, dqkv, N, H, D,
-                       (uint32_t)bytes, scale, scale_log2);
+                       (uint32_t)bytes, scale, scale_log2, remap);
     BVC_CHECK_HIP(hipGetLastError());
     return BVC_OK;
 }

@@ -23,6 +23,7 @@ int launch_ln_bwd(const bf16_t* dy, const float* x, RowMap rm, const float* mean
 int launch_colsum_bf16(const bf16_t* X, int M, int N, int ld, float alpha, float* out, hipStream_t s);
 int launch_colsum_bf16_scaled(const bf16_t* X, int M, int N, int ld, float alpha, const float* alpha_dev, float* out, hipStream_t s);
 int launch_colsum_f32(const float* X, RowMap rm, int M, int D, float* out, hipStream_t s);
+int launch_token_mean(const float* x, int B, int N, int D, float* out, hipStream_t s);
 int launch_cast_bf16(const float* in, bf16_t* out, size_t n, hipStream_t s);
 int launch_gather_rows_bf16(const float* in, RowMap rm, bf16_t* out, int M, int D, hipStream_t s);
 int launch_mask_index(const uint8_t* mask, int B, int L, int nvis, int nmask, int* vis_idx, int* msk_idx, int* status, hipStream_t s);

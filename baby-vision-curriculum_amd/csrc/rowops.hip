@@ -195,6 +195,28 @@ __global__ __launch_bounds__(256) void colsum_f32_kernel(const float* __restrict
     if (n < D) atomicAdd(out + n, (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]));
 }
 
+// out[b][d] = mean over the N tokens of clip b (sequence_output.mean(1), HF VideoMAEForVideoClassification.forward);
+// grid (ceil(D/64), B); thread = 4 columns x one of 16 row phases; fixed summation order (no atomics)
+__global__ __launch_bounds__(256) void token_mean_kernel(const float* __restrict__ x, int N, int D, float* __restrict__ out) {
+    __shared__ float red[16][64];
+    const int cg = threadIdx.x & 15, rp = threadIdx.x >> 4;
+    const int col = blockIdx.x * 64 + cg * 4;
+    const float* xb = x + (size_t)blockIdx.y * N * D;
+    f32x4 acc = {0, 0, 0, 0};
+    if (col < D)
+        for (int m = rp; m < N; m += 16) acc += *reinterpret_cast<const f32x4*>(xb + (size_t)m * D + col);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[rp][cg * 4 + e] = acc[e];
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t += red[r][threadIdx.x];
+        const int n = blockIdx.x * 64 + threadIdx.x;
+        if (n < D) out[(size_t)blockIdx.y * D + n] = t / (float)N;
+    }
+}
+
 // ============================================================================ elementwise
 __global__ void cast_f32_bf16_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, size_t n) {
     const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 8;
@@ -608,6 +630,13 @@ int launch_colsum_f32(const float* X, RowMap rm, int M, int D, float* out, hipSt
     BVC_REQUIRE(D % 4 == 0, "colsum_f32: D must be a multiple of 4");
     const int RB = 256;
     hipLaunchKernelGGL(colsum_f32_kernel, dim3((D + 255) / 256, (M + RB - 1) / RB), dim3(256), 0, s, X, rm, M, D, out, RB);
+    BVC_CHECK_HIP(hipGetLastError());
+    return BVC_OK;
+}
+
+int launch_token_mean(const float* x, int B, int N, int D, float* out, hipStream_t s) {
+    BVC_REQUIRE(D % 4 == 0, "token_mean: D must be a multiple of 4");
+    hipLaunchKernelGGL(token_mean_kernel, dim3((D + 63) / 64, B), dim3(256), 0, s, x, N, D, out);
     BVC_CHECK_HIP(hipGetLastError());
     return BVC_OK;
 }

@@ -129,19 +129,23 @@ GemmProblem gemm(const bf16_t* A, size_t a_elems, int lda, const bf16_t* B, size
 // Measured (profiles/r01_b_microbench.json): when the 128x128 tiles alone cover the chip (encoder layer: 432)
 // use them unsplit; otherwise 64x64 tiles with just enough K-splits for ~850 workgroups (decoder layer: 432 x 2).
 int plan_dw(GemmProblem* g, int n) {
-    int t128 = 0, t64 = 0;
-    for (int i = 0; i < n; ++i) {
-        t128 += ((g[i].M + 127) / 128) * ((g[i].N + 127) / 128);
-        t64 += ((g[i].M + 63) / 64) * ((g[i].N + 63) / 64);
+    // Largest tile that still gives about one full wave of blocks (256 CUs x 2 resident) once K is split; the split is capped
+    // at 12 (each split adds one f32 atomic pass over the output) and at 8 K-steps per block.  Fitted to the same-box sweep
+    // in profiles/r01_d_dw_sweep.txt (tools/dw_sweep.py): dec layer group 128x128 split 4 = 125 us vs 64x64 split 2 = 155 us.
+    static const int bm[3] = {128, 128, 64}, bn[3] = {128, 64, 64};
+    int ksteps = 1 << 30;
+    for (int i = 0; i < n; ++i) ksteps = std::min(ksteps, (g[i].K + 63) / 64);
+    const int cap = std::max(1, std::min(12, ksteps / 8));
+    int tile = 2, split = 1;
+    for (int t = 0; t < 3; ++t) {
+        int tiles = 0;
+        for (int i = 0; i < n; ++i) tiles += ((g[i].M + bm[t] - 1) / bm[t]) * ((g[i].N + bn[t] - 1) / bn[t]);
+        const int s = std::max(1, std::min(cap, (480 + tiles / 2) / tiles));
+        tile = t; split = s;
+        if (tiles * s >= 400) break;
     }
-    if (t128 >= 400) return 0;
-    for (int i = 0; i < n; ++i) {
-        const int ksteps = (g[i].K + 63) / 64;
-        int s = (864 + t64 / 2) / t64;
-        s = std::min(s, std::max(1, ksteps / 16));
-        g[i].split_k = std::max(1, s);
-    }
-    return 2;
+    for (int i = 0; i < n; ++i) g[i].split_k = split;
+    return tile;
 }
 
 int layer_forward(Work& w, Stack& s, int li, const LayerOff& o, const float* x_in, float* x_out, int B, int N, hipStream_t st) {

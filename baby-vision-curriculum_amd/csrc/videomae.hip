@@ -17,6 +17,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -363,6 +364,105 @@ int bvc_videomae_tap(bvc_ctx* c, const char* name, float* dst, int64_t capacity,
     *numel = (int64_t)n;
     BVC_REQUIRE((int64_t)n <= capacity, "tap: destination holds %lld elements, '%s' has %lld", (long long)capacity, name, (long long)n);
     BVC_CHECK_HIP(hipMemcpyAsync(dst, src, n * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return BVC_OK;
+}
+
+// ------------------------------------------------------------------ encoder-only inference (embedding extraction)
+// Replaces VideoMAEForVideoClassification(num_labels=0).forward as benchmarks/compute_embeddings_videomae.py:78-96,253-264
+// uses it between curriculum stages: all tokens (no mask) -> encoder -> mean over tokens -> fc_norm (HF
+// VideoMAEForVideoClassification.forward; VideoMAEModel.layernorm is None under use_mean_pooling).  Forward only: ONE set of
+// layer activations is reused by every layer, so the working set is independent of depth.
+struct bvc_encoder_ctx {
+    bvc_videomae_config cfg;
+    Layout lay;
+    int max_batch, L, P;
+    Arena arena;
+    Work w;            // parameter views only; no backward scratch is allocated
+    Stack st;          // one LayerAct
+    float *pos_enc, *xa, *xb, *pooled, *mean, *rstd;
+    bf16_t *wbf, *Ape;
+    int* idx_all;
+};
+
+void bvc_videomae_encoder_destroy(bvc_encoder_ctx* c) {
+    if (!c) return;
+    c->arena.release();
+    delete c;
+}
+
+int64_t bvc_videomae_encoder_param_numel(const bvc_videomae_config* cfg) {
+    if (!cfg || check_config(*cfg) != BVC_OK) return BVC_ERR_INVALID;
+    return make_layout(*cfg).e2d_w;    // the "videomae.*" entries are the leading part of the pre-training layout
+}
+
+int bvc_videomae_encoder_create(const bvc_videomae_config* cfg, int max_batch, bvc_encoder_ctx** out) {
+    BVC_REQUIRE(cfg && out && max_batch >= 1, "encoder_create: bad argument");
+    TRY(check_config(*cfg));
+    bvc_encoder_ctx* c = new bvc_encoder_ctx();
+    c->cfg = *cfg;
+    c->lay = make_layout(*cfg);
+    c->max_batch = max_batch;
+    const int g = cfg->image_size / cfg->patch_size;
+    c->L = (cfg->num_frames / cfg->tubelet_size) * g * g;
+    c->P = cfg->num_channels * cfg->tubelet_size * cfg->patch_size * cfg->patch_size;
+    const size_t M = (size_t)max_batch * c->L;
+    const int D = cfg->hidden_size, I = cfg->intermediate_size, H = cfg->num_attention_heads;
+    int rc = BVC_OK;
+    auto fail = [&](int r) { bvc_videomae_encoder_destroy(c); return r; };
+    if (M * (size_t)std::max(I, c->P) * 2 >= 0xffffffffull) { set_error("encoder_create: max_batch %d needs operands above 4 GiB", max_batch); return fail(BVC_ERR_INVALID); }
+#define A(expr) if ((rc = (expr)) != BVC_OK) return fail(rc)
+    A(c->arena.alloc(&c->pos_enc, (size_t)c->L * D));
+    A(c->arena.alloc(&c->wbf, (size_t)c->lay.e2d_w));
+    A(c->arena.alloc(&c->idx_all, M));
+    A(c->arena.alloc(&c->Ape, M * c->P));
+    A(alloc_stack(c->arena, c->st, D, I, H, 1, cfg->layer_norm_eps, M, (size_t)max_batch * H * c->L));
+    A(c->arena.alloc(&c->xa, M * D));
+    A(c->arena.alloc(&c->xb, M * D));
+    A(c->arena.alloc(&c->pooled, (size_t)max_batch * D));
+    A(c->arena.alloc(&c->mean, (size_t)max_batch));
+    A(c->arena.alloc(&c->rstd, (size_t)max_batch));
+    A(launch_iota_mod(c->idx_all, (int)M, c->L, nullptr));
+#undef A
+    std::vector<float> tab;
+    sinusoid(tab, c->L, D);
+    if (hipMemcpy(c->pos_enc, tab.data(), tab.size() * 4, hipMemcpyHostToDevice) != hipSuccess) { set_error("encoder_create: pos upload failed"); return fail(BVC_ERR_HIP); }
+    *out = c;
+    return BVC_OK;
+}
+
+int bvc_videomae_encode(bvc_encoder_ctx* c, const float* pixels, int batch, const float* params, const float* fc_norm_w,
+                        const float* fc_norm_b, float fc_norm_eps, float* tokens, float* pooled, void* stream) {
+    BVC_REQUIRE(c && pixels && params && (tokens || pooled), "encode: null argument");
+    BVC_REQUIRE(batch >= 1 && batch <= c->max_batch, "encode: batch %d outside [1, %d]", batch, c->max_batch);
+    BVC_REQUIRE((fc_norm_w == nullptr) == (fc_norm_b == nullptr), "encode: fc_norm weight and bias go together");
+    hipStream_t st = (hipStream_t)stream;
+    const bvc_videomae_config& cf = c->cfg;
+    const Layout& L = c->lay;
+    const int B = batch, N = c->L, M = B * N, D = cf.hidden_size, P = c->P;
+    c->w.params = params;
+    c->w.wbf = c->wbf;
+    const PatchGeom pg{cf.num_frames, cf.num_channels, cf.image_size, cf.image_size, cf.tubelet_size, cf.patch_size};
+    TRY(launch_cast_bf16(params, c->wbf, (size_t)L.e2d_w, st));
+    TRY(launch_gather_patches(pixels, c->idx_all, c->Ape, B, N, pg, st));
+    float* x = c->xa;
+    float* y = c->xb;
+    {
+        GemmProblem p = gemm(c->Ape, (size_t)M * P, P, c->wbf + L.pe_w, (size_t)D * P, P, M, D, P, EPI_POS, x, D);
+        p.bias = params + L.pe_b; p.rowtok = c->idx_all; p.pos = c->pos_enc;
+        TRY(launch_gemm(&p, 1, GEMM_NT, -1, st));
+    }
+    const int nl = (int)L.enc.size();
+    for (int i = 0; i < nl; ++i) {
+        float* dst = (i + 1 == nl && tokens) ? tokens : y;     // the last layer writes straight into the caller's buffer
+        TRY(layer_forward(c->w, c->st, 0, L.enc[i], x, dst, B, N, st));
+        if (dst == y) std::swap(x, y); else x = dst;
+    }
+    if (pooled) {
+        float* mp = fc_norm_w ? c->pooled : pooled;
+        TRY(launch_token_mean(x, B, N, D, mp, st));
+        if (fc_norm_w)
+            TRY(launch_ln_fwd(mp, identity_rows(), fc_norm_w, fc_norm_b, nullptr, c->mean, c->rstd, B, D, fc_norm_eps, st, pooled));
+    }
     return BVC_OK;
 }
 

@@ -211,6 +211,101 @@ class VideoMAEForPreTraining(FlatParamModule):
         return buf[: n.value]
 
 
+@dataclass
+class ImageClassifierOutput:
+    loss: Optional[torch.Tensor] = None
+    logits: Optional[torch.Tensor] = None
+    hidden_states: Optional[tuple] = None
+    attentions: Optional[tuple] = None
+    last_hidden_state: Optional[torch.Tensor] = None
+
+
+class VideoMAEForVideoClassification(FlatParamModule):
+    """Encoder-only inference model of the embedding benchmark (benchmarks/compute_embeddings_videomae.py:78-96,253-264).
+
+    Same sub-module tree / state-dict keys as transformers.VideoMAEForVideoClassification: ``videomae.embeddings.*``,
+    ``videomae.encoder.*`` (so ``adapt_videomae``'s ``target.videomae.embeddings.load_state_dict(source.videomae.embeddings
+    .state_dict())`` works against a pre-training model), ``fc_norm.*`` and, for ``num_labels > 0``, ``classifier.*``.
+    ``forward(pixel_values).logits`` = classifier(fc_norm(mean over all tokens of the encoder output)); the reference uses
+    ``num_labels=0`` (classifier = Identity), i.e. the logits ARE the embedding.  Forward only (no autograd).
+    """
+
+    def __init__(self, config: VideoMAEConfig):
+        super().__init__()
+        if not getattr(config, "use_mean_pooling", True):
+            raise ValueError("only use_mean_pooling=True (the reference's setting) is implemented")
+        self.config = config
+        self.num_labels = int(getattr(config, "num_labels", 2))
+        full, _ = param_layout(config)
+        cc = config.to_c()
+        numel = int(_lib.lib().bvc_videomae_encoder_param_numel(ctypes.byref(cc)))
+        layout = [e for e in full if e[0].startswith("videomae.")]
+        assert sum(int(torch.Size(e[2]).numel()) for e in layout) == numel
+        std = config.initializer_range
+
+        def init(name, shape):
+            if len(shape) >= 2:
+                return torch.empty(shape).normal_(0.0, std)
+            if name.endswith("layernorm_before.weight") or name.endswith("layernorm_after.weight"):
+                return torch.ones(shape)
+            return torch.zeros(shape)
+
+        self._init_flat(layout, numel, init)
+        self.fc_norm = nn.LayerNorm(config.hidden_size)    # as in HF: default eps 1e-5, not config.layer_norm_eps
+        self.classifier = nn.Linear(config.hidden_size, self.num_labels) if self.num_labels > 0 else nn.Identity()
+        if self.num_labels > 0:
+            nn.init.normal_(self.classifier.weight, 0.0, std)
+            nn.init.zeros_(self.classifier.bias)
+        self._ctx = None
+        self._ctx_key = None
+
+    def _get_ctx(self, batch):
+        key = (batch, self._flat.device.index)
+        if self._ctx is not None and self._ctx_key[1] == key[1] and self._ctx_key[0] >= batch:
+            return self._ctx
+        self._free_ctx()
+        h = ctypes.c_void_p()
+        cc = self.config.to_c()
+        _lib.check(_lib.lib().bvc_videomae_encoder_create(ctypes.byref(cc), batch, ctypes.byref(h)), "bvc_videomae_encoder_create")
+        self._ctx, self._ctx_key = h, key
+        return h
+
+    def _free_ctx(self):
+        if self._ctx is not None:
+            _lib.lib().bvc_videomae_encoder_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self._free_ctx()
+        except Exception:
+            pass
+
+    @torch.no_grad()
+    def forward(self, pixel_values=None, labels=None, output_last_hidden_state=False, **kwargs):
+        if labels is not None:
+            raise NotImplementedError("the classification loss / fine-tuning path is outside the pre-training hot path")
+        if pixel_values is None or not pixel_values.is_cuda:
+            raise _lib.BvcError("VideoMAEForVideoClassification runs on a GPU only (libbvc_hip.so has no CPU path)")
+        cfg = self.config
+        B, T, C, H, W = pixel_values.shape
+        if C != cfg.num_channels or H != cfg.image_size or W != cfg.image_size or T != cfg.num_frames:
+            raise ValueError(f"Input size ({T}x{C}x{H}*{W}) doesn't match model ({cfg.num_frames}x{cfg.num_channels}x{cfg.image_size}*{cfg.image_size}).")
+        dev = pixel_values.device
+        self._ensure_flat(dev)
+        pixels = pixel_values.detach().to(dtype=torch.float32).contiguous()
+        h = self._get_ctx(B)
+        w = self.fc_norm.weight.detach().to(device=dev, dtype=torch.float32).contiguous()
+        b = self.fc_norm.bias.detach().to(device=dev, dtype=torch.float32).contiguous()
+        pooled = torch.empty((B, cfg.hidden_size), dtype=torch.float32, device=dev)
+        tokens = torch.empty((B, cfg.seq_length, cfg.hidden_size), dtype=torch.float32, device=dev) if output_last_hidden_state else None
+        _lib.check(_lib.lib().bvc_videomae_encode(
+            h, pixels.data_ptr(), B, self._flat.data_ptr(), w.data_ptr(), b.data_ptr(), float(self.fc_norm.eps),
+            tokens.data_ptr() if tokens is not None else None, pooled.data_ptr(), _lib.current_stream_ptr()), "bvc_videomae_encode")
+        logits = self.classifier(pooled)
+        return ImageClassifierOutput(logits=logits, last_hidden_state=tokens)
+
+
 def get_config(image_size, args):
     """pretrain_videomae.py:43-58 (only architecture='base' exists in the reference)."""
     if getattr(args, "architecture", "base") != "base":

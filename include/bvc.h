@@ -93,6 +93,26 @@ int bvc_videomae_backward(bvc_ctx* ctx, const float* grad_loss_dev, float* grads
 int bvc_videomae_tap(bvc_ctx* ctx, const char* name, float* dst_dev, int64_t capacity, int64_t* numel, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Encoder-only inference: the embedding extraction that runs between curriculum stages.
+ * Replaces transformers.VideoMAEForVideoClassification(num_labels=0).forward as called at
+ * benchmarks/compute_embeddings_videomae.py:78-96 (model assembly) and :253-264 (xmodel(pixel_values=inputs).logits):
+ * every token (no mask) -> patch embedding + sinusoid -> encoder layers -> mean over tokens -> fc_norm LayerNorm.
+ * `params` is a flat f32 buffer holding the "videomae.*" entries in the order of bvc_videomae_param_info (they are the
+ * leading bvc_videomae_encoder_param_numel() elements of the pre-training layout, so a pre-training buffer can be passed
+ * as is).  Forward only; the context owns workspaces for max_batch clips. */
+typedef struct bvc_encoder_ctx bvc_encoder_ctx;
+int64_t bvc_videomae_encoder_param_numel(const bvc_videomae_config* cfg);
+int bvc_videomae_encoder_create(const bvc_videomae_config* cfg, int max_batch, bvc_encoder_ctx** out);
+void bvc_videomae_encoder_destroy(bvc_encoder_ctx* ctx);
+/*   pixels_dev   f32 [batch][T][C][H][W]
+ *   fc_norm_w/b  f32 [hidden] or both NULL (then `pooled` is the plain token mean)
+ *   tokens_dev   f32 [batch][L][hidden] last_hidden_state, or NULL
+ *   pooled_dev   f32 [batch][hidden] = fc_norm(mean over tokens), or NULL                                     */
+int bvc_videomae_encode(bvc_encoder_ctx* ctx, const float* pixels_dev, int batch, const float* params_dev,
+                        const float* fc_norm_w, const float* fc_norm_b, float fc_norm_eps, float* tokens_dev,
+                        float* pooled_dev, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * JEPA encoder and predictor (pretraining/predictive/vision_transformer.py).  Same conventions as above: flat f32
  * parameter / gradient buffers whose entries carry the reference's state-dict keys (pos_embed, patch_embed.proj.*,
  * blocks.N.{norm1,attn.qkv,attn.proj,norm2,mlp.fc1,mlp.fc2}.*, norm.* / mask_token, predictor_pos_embed,

@@ -145,12 +145,16 @@ def simclr_fixture():
     two loss functions themselves - which use only torch/numpy - are the reference's own code."""
     import types
     from oracle import simclr_oracle as so
+    stubs = []
     for name in ("torchvision", "torchvision.transforms", "torchvision.models", "torchvision.io", "torchvision.datasets",
                  "torchvision.transforms.functional"):
         if name not in sys.modules:
             sys.modules[name] = types.ModuleType(name)
+            stubs.append(name)
     sys.path.insert(0, os.path.join(REF, "pretraining", "contrastive"))
     import pretrain_simclr as ref
+    for name in stubs:      # transformers probes for torchvision later; the stand-ins must not outlive this import
+        del sys.modules[name]
     cases = []
     for B, p, seed in [(8, 128, 0), (32, 512, 1), (4, 64, 2)]:
         feats = so.synthetic_features(2 * B, p, seed).requires_grad_(True)
@@ -245,12 +249,50 @@ def jepa_fixture():
                    "cases": cases, "mask_collator": mc_cases}, f, indent=1)
 
 
+def embedding_fixture():
+    """Encoder-only inference (benchmarks/compute_embeddings_videomae.py:78-96,253-264): the reference assembles
+    VideoMAEForVideoClassification(num_labels=0) from a pre-training model's embeddings + encoder and reads `.logits`."""
+    import transformers
+    cases = {}
+    for name, cfg, batch, seed in (("tiny", vo.TINY, 3, 5), ("base", vo.BASE, 1, 6)):
+        params = vo.make_params(cfg, seed=2)
+        source, ver = hf_model(cfg, params)
+        tc = transformers.VideoMAEConfig(
+            image_size=cfg.image_size, patch_size=cfg.patch_size, num_channels=cfg.num_channels, num_frames=cfg.num_frames,
+            tubelet_size=cfg.tubelet_size, hidden_size=cfg.hidden_size, num_hidden_layers=cfg.num_hidden_layers,
+            num_attention_heads=cfg.num_attention_heads, intermediate_size=cfg.intermediate_size, num_labels=0)
+        target = transformers.VideoMAEForVideoClassification(config=tc)
+        target.videomae.embeddings.load_state_dict(source.videomae.embeddings.state_dict())     # adapt_videomae, :59-66
+        target.videomae.encoder.load_state_dict(source.videomae.encoder.state_dict())
+        g = torch.Generator().manual_seed(77)
+        fw = 1 + 0.1 * torch.randn(cfg.hidden_size, generator=g)
+        fb = 0.05 * torch.randn(cfg.hidden_size, generator=g)
+        with torch.no_grad():
+            target.fc_norm.weight.copy_(fw)
+            target.fc_norm.bias.copy_(fb)
+        target.eval()
+        pixels, _ = vo.synthetic_batch(cfg, batch, seed, 0.9)
+        with torch.no_grad():
+            out = target(pixel_values=pixels, output_hidden_states=False)
+            ref = out.logits
+            pooled, tokens = vo.encode(cfg, params, pixels, fw, fb, float(target.fc_norm.eps))
+        e = float((pooled - ref).norm() / ref.norm())
+        assert e < 2e-5, (name, "embedding", e)
+        print(f"[embed {name}] oracle vs transformers {ver}: rel {e:.2e}")
+        cases[name] = {"batch": batch, "seed": seed, "weight_seed": 2, "fc_norm_seed": 77, "fc_norm_eps": float(target.fc_norm.eps),
+                       "pixels": summarize(pixels), "embedding": summarize(ref, n=16), "tokens": summarize(tokens),
+                       "embedding_row0": [float(x) for x in ref[0, :64]]}
+    with open(os.path.join(GOLD, "videomae_embedding.json"), "w") as f:
+        json.dump({"transformers": ver, "torch": torch.__version__, "cases": cases}, f, indent=1)
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     torch.manual_seed(0)
     mask_fixture()
     simclr_fixture()
     jepa_fixture()
+    embedding_fixture()
     if "--only-new" in sys.argv:
         return
     one_case("tiny_s0", vo.TINY, batch=2, seed=0, mask_ratio=0.75)

@@ -268,6 +268,24 @@ def forward(cfg: OracleConfig, p: "Dict[str, torch.Tensor]", pixel_values: torch
     return loss, logits, labels
 
 
+def encode(cfg: OracleConfig, p: "Dict[str, torch.Tensor]", pixel_values: torch.Tensor, fc_norm_w=None, fc_norm_b=None,
+           fc_norm_eps: float = 1e-5):
+    """Encoder-only inference = VideoMAEForVideoClassification(num_labels=0).forward in fp32
+    (benchmarks/compute_embeddings_videomae.py:78-96,253-264): every token, no mask, encoder, mean over tokens, fc_norm.
+    Returns (embedding (B, hidden), last_hidden_state (B, L, hidden))."""
+    D, L = cfg.hidden_size, cfg.seq_len
+    x = F.conv3d(pixel_values.permute(0, 2, 1, 3, 4), p["videomae.embeddings.patch_embeddings.projection.weight"],
+                 p["videomae.embeddings.patch_embeddings.projection.bias"],
+                 stride=(cfg.tubelet_size, cfg.patch_size, cfg.patch_size)).flatten(2).transpose(1, 2)
+    x = x + sinusoid_table(L, D)[None]
+    for i in range(cfg.num_hidden_layers):
+        x = _layer(x, p, f"videomae.encoder.layer.{i}.", cfg.num_attention_heads, cfg.layer_norm_eps, None, "")
+    pooled = x.mean(1)
+    if fc_norm_w is not None:
+        pooled = F.layer_norm(pooled, (D,), fc_norm_w, fc_norm_b, fc_norm_eps)
+    return pooled, x
+
+
 GRAD_PROBES = (  # loggingtools.py:107-116  (grad-EFL, grad-ELL, grad-DLL)
     "videomae.embeddings.patch_embeddings.projection.weight",
     "encoder_to_decoder.weight",

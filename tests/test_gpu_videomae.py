@@ -224,3 +224,68 @@ def test_state_dict_round_trip_and_keys():
         assert torch.equal(sd[k], params[k])
     m2 = _model(cfg, sd)
     assert float(m2(pixels.to(dev), bool_masked_pos=mask.to(dev)).loss) == l0
+
+
+# ------------------------------------------------------------------ encoder-only inference
+def _fc_norm(cfg, seed):
+    g = torch.Generator().manual_seed(seed)
+    return 1 + 0.1 * torch.randn(cfg.hidden_size, generator=g), 0.05 * torch.randn(cfg.hidden_size, generator=g)
+
+
+def _classifier(cfg, params, fw, fb):
+    kw = {k: v for k, v in cfg.__dict__.items() if k != "decoder_norm_eps"}
+    m = bvc.VideoMAEForVideoClassification(bvc.VideoMAEConfig(num_labels=0, **kw))
+    missing = m.load_state_dict({k: v for k, v in params.items() if k.startswith("videomae.")}, strict=False)
+    assert sorted(missing.missing_keys) == ["fc_norm.bias", "fc_norm.weight"] and not missing.unexpected_keys
+    with torch.no_grad():
+        m.fc_norm.weight.copy_(fw)
+        m.fc_norm.bias.copy_(fb)
+    return m.to(dev).eval()
+
+
+@pytest.mark.parametrize("case", ["tiny", "base"])
+def test_embedding_matches_oracle_and_fixture(golden_dir, case):
+    """xmodel(pixel_values=inputs).logits of benchmarks/compute_embeddings_videomae.py:253-264.  bf16 operands, f32
+    statistics: embedding within 2e-2 relative L2 of the fp32 oracle and of the transformers fixture."""
+    fx = json.load(open(os.path.join(golden_dir, "videomae_embedding.json")))["cases"][case]
+    cfg = vo.TINY if case == "tiny" else vo.BASE
+    params = vo.make_params(cfg, seed=fx["weight_seed"])
+    fw, fb = _fc_norm(cfg, fx["fc_norm_seed"])
+    pixels, _ = vo.synthetic_batch(cfg, fx["batch"], fx["seed"], 0.9)
+    with torch.no_grad():
+        ref, ref_tok = vo.encode(cfg, params, pixels, fw, fb, fx["fc_norm_eps"])
+    m = _classifier(cfg, params, fw, fb)
+    out = m(pixel_values=pixels.to(dev), output_last_hidden_state=True)
+    emb, tok = out.logits.float().cpu(), out.last_hidden_state.float().cpu()
+    e_emb = float((emb - ref).norm() / ref.norm())
+    e_tok = float((tok - ref_tok).norm() / ref_tok.norm())
+    e_fx = float((emb[0, :64] - torch.tensor(fx["embedding_row0"])).norm() / torch.tensor(fx["embedding_row0"]).norm())
+    _log(f"[embed {case}] embedding rel {e_emb:.2e}, tokens rel {e_tok:.2e}, vs transformers fixture row0 {e_fx:.2e}")
+    assert e_emb < 2e-2 and e_tok < 2e-2 and e_fx < 2e-2
+    assert tuple(emb.shape) == (fx["batch"], cfg.hidden_size)
+
+
+def test_embedding_from_pretraining_model_like_adapt_videomae():
+    """adapt_videomae (compute_embeddings_videomae.py:59-66): sub-module load_state_dict from a pre-training model; a
+    smaller batch on a larger context; batch independence (clip i's embedding does not depend on its neighbours)."""
+    cfg = vo.TINY
+    params = vo.make_params(cfg, seed=3)
+    src = _model(cfg, params)
+    kw = {k: v for k, v in cfg.__dict__.items() if k != "decoder_norm_eps"}
+    tgt = bvc.VideoMAEForVideoClassification(bvc.VideoMAEConfig(num_labels=0, **kw))
+    tgt.videomae.embeddings.load_state_dict(src.videomae.embeddings.state_dict())
+    tgt.videomae.encoder.load_state_dict(src.videomae.encoder.state_dict())
+    assert torch.all(tgt.videomae.embeddings.patch_embeddings.projection.weight.cpu()
+                     == src.videomae.embeddings.patch_embeddings.projection.weight.cpu())
+    tgt = tgt.to(dev).eval()
+    pixels, _ = vo.synthetic_batch(cfg, 5, 11, 0.75)
+    with torch.no_grad():
+        ref, _ = vo.encode(cfg, params, pixels, torch.ones(cfg.hidden_size), torch.zeros(cfg.hidden_size), 1e-5)
+    big = tgt(pixel_values=pixels.to(dev)).logits.float().cpu()
+    small = tgt(pixel_values=pixels[1:3].to(dev)).logits.float().cpu()
+    assert float((big - ref).norm() / ref.norm()) < 2e-2
+    assert torch.equal(big[1:3], small)
+    with pytest.raises(Exception):
+        tgt(pixel_values=pixels)          # CPU tensor: no CPU path
+    with pytest.raises(ValueError):
+        tgt(pixel_values=pixels[:, :2].to(dev))

@@ -92,3 +92,22 @@ def test_sgd_nesterov_restates_torch_optim():
         vo.sgd_nesterov_step(mine, g, bufs, lr=0.1, momentum=0.9)
         for k in ref:
             torch.testing.assert_close(mine[k], ref[k].detach(), rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("case", ["tiny", "base"])
+def test_oracle_encode_matches_transformers_fixture(golden_dir, case):
+    """Encoder-only inference (benchmarks/compute_embeddings_videomae.py:78-96,253-264): oracle.encode against the
+    VideoMAEForVideoClassification(num_labels=0) logits recorded by oracle/make_golden.py."""
+    fx = json.load(open(os.path.join(golden_dir, "videomae_embedding.json")))["cases"][case]
+    cfg = vo.TINY if case == "tiny" else vo.BASE
+    params = vo.make_params(cfg, seed=fx["weight_seed"])
+    g = torch.Generator().manual_seed(fx["fc_norm_seed"])
+    fw = 1 + 0.1 * torch.randn(cfg.hidden_size, generator=g)
+    fb = 0.05 * torch.randn(cfg.hidden_size, generator=g)
+    pixels, _ = vo.synthetic_batch(cfg, fx["batch"], fx["seed"], 0.9)
+    assert abs(float(pixels.double().norm()) - fx["pixels"]["l2"]) < 1e-6 * fx["pixels"]["l2"]
+    with torch.no_grad():
+        emb, tokens = vo.encode(cfg, params, pixels, fw, fb, fx["fc_norm_eps"])
+    assert abs(float(emb.double().norm()) - fx["embedding"]["l2"]) < 1e-5 * fx["embedding"]["l2"]
+    np.testing.assert_allclose(emb[0, :64].numpy(), np.array(fx["embedding_row0"]), rtol=0, atol=2e-5)
+    assert abs(float(tokens.double().norm()) - fx["tokens"]["l2"]) < 1e-5 * fx["tokens"]["l2"]

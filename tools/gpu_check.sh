@@ -32,14 +32,22 @@ for step in "$@"; do
     benchddp) BVC_FORCE_DDP=1 run benchddp 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --steps 20 --warmup 3 --no-cpu-baseline ;;
     benchov) BVC_DW_OVERLAP=1 run benchov 300 python bench.py --no-cpu-baseline ;;
     micro) run micro 400 python tools/microbench.py ;;
+    dwsweep) run dwsweep 400 python tools/dw_sweep.py ;;
     probe) run probe 300 python tools/gemm_probe.py ;;
     jepa) run jepa 400 python tools/bench_jepa.py ;;
+    encode) run encode 300 python tools/bench_encode.py ;;
     simclr) run simclr 400 python tools/bench_simclr.py ;;
     prof)  rm -rf $OUT/prof; cd /tmp
            run prof 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline
            cd $R
            find $OUT/prof -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/kernel_stats.csv
            find $OUT/prof -name "*kernel_trace.csv" -size +20M -delete ;;
+    traffic) rm -rf $OUT/pmct; cd /tmp
+           run traffic_rd 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmct/rd -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline
+           run traffic_wr 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmct/wr -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline
+           cd $R
+           run traffic 60 python tools/pmc_traffic.py $OUT/pmct/rd $OUT/pmct/wr 3 16 $OUT/traffic_b16.json
+           find $OUT/pmct -name "*.csv" -size +5M -delete ;;
     pmc_attn) rm -rf $OUT/pmc; cd /tmp
            run pmc_attn1 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d $OUT/pmc/a -- python3 $R/tools/attn_only.py
            run pmc_attn2 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS --output-format csv -d $OUT/pmc/b -- python3 $R/tools/attn_only.py

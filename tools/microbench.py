@@ -108,9 +108,16 @@ def main():
                     ms = timeit(lambda: G.run_gemm(descs, G.TN, tile, stg))
                     r = {"name": f"{tag} dW group", "tile": tile, "split": split, "lb": stg, "ms": round(ms, 4), "tflops": round(flops / ms / 1e9, 1)}
                     out.append(r); print(r, flush=True)
-    for (B, N, H) in [(Bc, 160, 12), (Bc, 1568, 6)]:
-        r = attn_case(B, N, H)
-        out.append(r); print(r, flush=True)
+    for (B, N, H) in [(Bc, 160, 12), (Bc, 1568, 6), (Bc, 1568, 12)]:
+        for plain in (0, 1):    # same-run A/B of the XCD-aware block map (attention.hip:attn_block)
+            if plain:
+                os.environ["BVC_ATTN_PLAIN_GRID"] = "1"
+            else:
+                os.environ.pop("BVC_ATTN_PLAIN_GRID", None)
+            r = attn_case(B, N, H)
+            r["grid"] = "plain" if plain else "xcd"
+            out.append(r); print(r, flush=True)
+    os.environ.pop("BVC_ATTN_PLAIN_GRID", None)
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", "micro.json"), "w") as f:
         json.dump(out, f, indent=1)

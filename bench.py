@@ -27,6 +27,22 @@ GFLOP_PER_CLIP = 202.295          # algorithmic fwd+bwd FLOPs per clip, BASELINE
 PEAK_BF16_TFLOPS = 2500.0         # dense bf16 MFMA peak, MI355X_MICROARCH.md
 
 
+def measured_traffic(batch):
+    """Fabric (HBM + Infinity-Cache) bytes per step from the committed PMC passes, or None.
+
+    bench.py cannot collect TCC counters on itself; `tools/gpu_check.sh traffic` runs THIS script under
+    `rocprofv3 --kernel-trace --pmc FETCH_SIZE` and again under `--pmc WRITE_SIZE` (separate passes, as the
+    microarchitecture guide prescribes) and tools/pmc_traffic.py reduces them (KiB -> bytes, FETCH_SIZE x2 on
+    gfx950) into profiles/traffic_b<batch>.json, which is what is reported here, per step like `achieved`."""
+    path = os.path.join(ROOT, "profiles", f"traffic_b{batch}.json")
+    try:
+        with open(path) as f:
+            t = json.load(f)
+        return float(t["hbm_bytes_per_step"]), os.path.relpath(path, ROOT)
+    except (OSError, KeyError, ValueError):
+        return None, None
+
+
 def synthetic_clips(batch, seed, device):
     """uint8 ~ U{0..255} frames through the loader's transform (x/255 - 0.5)/0.25 (homeview.py:218-231)."""
     g = torch.Generator().manual_seed(seed)
@@ -158,6 +174,7 @@ def main():
         clips_s = world * B * args.steps / dt
         step_ms_gpu = gpu_ms / args.steps
         achieved = GFLOP_PER_CLIP * 1e9 * B / (step_ms_gpu * 1e-3) / 1e12
+        traffic, traffic_src = measured_traffic(B) if world == 1 else (None, None)
         line = {
             "metric": "video clips/sec (node) VideoMAE-base 16x224^2 bf16 pretraining",
             "value": round(clips_s, 2), "unit": "clips/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -168,7 +185,7 @@ def main():
                        "clips_per_gpu": B, "global_batch": world * B, "parallelism": f"dp{world}",
                        "weights": "random init N(0,0.02), seed 0", "final_loss": round(final_loss, 5)},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                         "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "one training step = the fwd+bwd kernel sequence of libbvc_hip.so on the compute stream",
                          "flops_per_launch": GFLOP_PER_CLIP * 1e9 * B, "launch_ms": round(step_ms_gpu, 4)},
         }

@@ -9,6 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libbvc_hip.so")
 
 c_void_p, c_int, c_int64, c_float, c_char_p = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_char_p
+c_double = ctypes.c_double
 
 
 class BvcError(RuntimeError):
@@ -31,6 +32,27 @@ class VitConfigC(ctypes.Structure):
 
 class PredictorConfigC(ctypes.Structure):
     _fields_ = [(n, c_int) for n in ("seq_len", "embed_dim", "pred_dim", "depth", "num_heads", "mlp_hidden")] + [("eps", c_float)]
+
+
+class PixelFormatC(ctypes.Structure):
+    _fields_ = [("dtype", c_int), ("mean", c_float * 4), ("std", c_float * 4)]
+
+
+def pixel_format(pixel_values, mean, std, channels):
+    """None for f32 input (already normalised); a PixelFormatC for uint8 frames to be normalised on the GPU."""
+    import torch
+    if pixel_values.dtype != torch.uint8:
+        return None
+    def per_channel(v):
+        v = list(v) if hasattr(v, "__len__") else [float(v)] * channels
+        if len(v) != channels or channels > 4:
+            raise ValueError("pixel mean / std need one value per channel (at most 4 channels)")
+        return v + [0.0] * (4 - channels)
+    f = PixelFormatC()
+    f.dtype = 1
+    f.mean = (c_float * 4)(*per_channel(mean))
+    f.std = (c_float * 4)(*[x if i < channels else 1.0 for i, x in enumerate(per_channel(std))])
+    return f
 
 
 class GemmDesc(ctypes.Structure):
@@ -62,12 +84,16 @@ SYMBOLS = {
     "bvc_videomae_create": (c_int, [ctypes.POINTER(VideoMAEConfigC), c_int, c_int, ctypes.POINTER(c_void_p)]),
     "bvc_videomae_destroy": (None, [c_void_p]),
     "bvc_videomae_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "bvc_videomae_forward_px": (c_int, [c_void_p, c_void_p, ctypes.POINTER(PixelFormatC), c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                                        c_void_p]),
     "bvc_videomae_backward": (c_int, [c_void_p, c_void_p, c_void_p, BUCKET_FN, c_void_p, c_void_p]),
     "bvc_videomae_tap": (c_int, [c_void_p, c_char_p, c_void_p, c_int64, ctypes.POINTER(c_int64), c_void_p]),
     "bvc_videomae_encoder_param_numel": (c_int64, [ctypes.POINTER(VideoMAEConfigC)]),
     "bvc_videomae_encoder_create": (c_int, [ctypes.POINTER(VideoMAEConfigC), c_int, ctypes.POINTER(c_void_p)]),
     "bvc_videomae_encoder_destroy": (None, [c_void_p]),
     "bvc_videomae_encode": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p]),
+    "bvc_videomae_encode_px": (c_int, [c_void_p, c_void_p, ctypes.POINTER(PixelFormatC), c_int, c_void_p, c_void_p, c_void_p, c_float,
+                                       c_void_p, c_void_p, c_void_p]),
     "bvc_vit_param_count": (c_int, [ctypes.POINTER(VitConfigC)]),
     "bvc_vit_param_numel": (c_int64, [ctypes.POINTER(VitConfigC)]),
     "bvc_vit_param_info": (c_int, [ctypes.POINTER(VitConfigC), c_int, ctypes.c_char_p, c_int, ctypes.POINTER(c_int64),
@@ -75,6 +101,7 @@ SYMBOLS = {
     "bvc_vit_create": (c_int, [ctypes.POINTER(VitConfigC), c_int, ctypes.POINTER(c_void_p)]),
     "bvc_vit_destroy": (None, [c_void_p]),
     "bvc_vit_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "bvc_vit_forward_px": (c_int, [c_void_p, c_void_p, ctypes.POINTER(PixelFormatC), c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "bvc_vit_backward": (c_int, [c_void_p, c_void_p, c_void_p, BUCKET_FN, c_void_p, c_void_p]),
     "bvc_predictor_param_count": (c_int, [ctypes.POINTER(PredictorConfigC)]),
     "bvc_predictor_param_numel": (c_int64, [ctypes.POINTER(PredictorConfigC)]),
@@ -89,6 +116,8 @@ SYMBOLS = {
     "bvc_op_smooth_l1_fwd": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "bvc_op_smooth_l1_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "bvc_op_ema": (c_int, [c_void_p, c_void_p, c_int64, c_float, c_void_p]),
+    "bvc_op_token_mean": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "bvc_op_token_mean_bwd": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "bvc_op_gemm": (c_int, [ctypes.POINTER(GemmDesc), c_int, c_int, c_int, c_int, c_void_p]),
     "bvc_op_gemm_num_tiles": (c_int, [ctypes.POINTER(GemmDesc), c_int]),
     "bvc_op_attention_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
@@ -105,6 +134,9 @@ SYMBOLS = {
     "bvc_op_nce_finalize": (c_int, [c_void_p, c_int, c_float, c_int64, c_void_p, c_void_p, c_void_p]),
     "bvc_op_sgd_step": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_int, c_int, c_int,
                                 c_void_p, c_void_p, c_int, c_void_p]),
+    "bvc_op_adam_prepare": (c_int, [c_void_p, c_double, c_double, c_double, c_void_p, c_void_p]),
+    "bvc_op_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_double, c_double, c_double, c_double, c_double,
+                                 c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "bvc_op_mask_index": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "bvc_op_gather_patches": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "bvc_op_pixel_labels": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),

@@ -194,7 +194,22 @@ int bvc_vit_create(const bvc_vit_config* cfg, int max_batch, bvc_vit_ctx** out) 
 //   out  f32 [B*ntok][D]
 int bvc_vit_forward(bvc_vit_ctx* c, const float* imgs, const int* idx, int batch, int ntok, const float* params, float* out,
                     void* stream) {
-    BVC_REQUIRE(c && imgs && params && out, "vit_forward: null argument");
+    return bvc_vit_forward_px(c, imgs, nullptr, idx, batch, ntok, params, out, stream);
+}
+
+int bvc_vit_forward_px(bvc_vit_ctx* c, const void* imgs_any, const bvc_pixel_format* fmt, const int* idx, int batch, int ntok,
+                       const float* params, float* out, void* stream) {
+    BVC_REQUIRE(c && imgs_any && params && out, "vit_forward: null argument");
+    PixelSrc imgs = pixels_f32((const float*)imgs_any);
+    if (fmt && fmt->dtype != BVC_PIXELS_F32) {
+        BVC_REQUIRE(fmt->dtype == BVC_PIXELS_U8 && c->cfg.num_channels <= 4, "vit_forward: unsupported pixel format");
+        imgs.is_u8 = 1;
+        for (int k = 0; k < 4; ++k) {
+            BVC_REQUIRE(fmt->std[k] != 0.f || k >= c->cfg.num_channels, "vit_forward: std[%d] is zero", k);
+            imgs.mean[k] = fmt->mean[k];
+            imgs.stdv[k] = k < c->cfg.num_channels ? fmt->std[k] : 1.f;
+        }
+    }
     BVC_REQUIRE(batch >= 1 && batch <= c->max_batch, "vit_forward: batch %d outside [1, %d]", batch, c->max_batch);
     if (!idx) ntok = c->L;
     BVC_REQUIRE(ntok >= 1 && ntok <= c->L, "vit_forward: ntok %d outside [1, %d]", ntok, c->L);
@@ -410,6 +425,15 @@ int bvc_op_smooth_l1_bwd(const float* z, const float* h, const float* grad_loss,
 int bvc_op_ema(float* target, const float* online, int64_t n, float momentum, void* stream) {
     BVC_REQUIRE(target && online && n >= 0, "op_ema: bad argument");
     return launch_ema(target, online, (size_t)n, momentum, (hipStream_t)stream);
+}
+
+int bvc_op_token_mean(const float* x, int batch, int ntok, int dim, float* out, void* stream) {
+    BVC_REQUIRE(x && out && batch > 0 && ntok > 0 && dim > 0, "op_token_mean: bad argument");
+    return launch_token_mean(x, batch, ntok, dim, out, (hipStream_t)stream);
+}
+int bvc_op_token_mean_bwd(const float* dmean, int batch, int ntok, int dim, float* dx, void* stream) {
+    BVC_REQUIRE(dmean && dx && batch > 0 && ntok > 0 && dim > 0, "op_token_mean_bwd: bad argument");
+    return launch_token_mean_bwd(dmean, batch, ntok, dim, dx, (hipStream_t)stream);
 }
 
 }  // extern "C"

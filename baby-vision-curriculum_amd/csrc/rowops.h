@@ -9,8 +9,18 @@ namespace bvc {
 struct RowMap { int rin, rout, roff; };
 static inline RowMap identity_rows() { return RowMap{0, 0, 0}; }
 
-// clip f32 [B][T][C][H][W]; tubes of ts frames x ps x ps pixels
+// clip [B][T][C][H][W]; tubes of ts frames x ps x ps pixels
 struct PatchGeom { int T, C, H, W, ts, ps; };
+
+// Where the pixels come from: f32 already normalised by the loader, or the loader's uint8 frames normalised on the fly as
+// (u / 255 - mean[c]) / std[c]  - the arithmetic of ToTensor + Normalize (homeview.py:221-230), same operation order, so the
+// two forms give bit-identical values while the uint8 one moves a quarter of the bytes over PCIe and out of HBM.
+struct PixelSrc {
+    const void* ptr;
+    int is_u8;
+    float mean[4], stdv[4];
+};
+static inline PixelSrc pixels_f32(const float* p) { return PixelSrc{p, 0, {0, 0, 0, 0}, {1, 1, 1, 1}}; }
 
 // gamma == nullptr: no affine.  y (bf16) and/or y32 (f32) receive the result; mean / rstd may be null.
 int launch_ln_fwd(const float* x, RowMap rm, const float* gamma, const float* beta, bf16_t* y, float* mean, float* rstd,
@@ -24,15 +34,20 @@ int launch_colsum_bf16(const bf16_t* X, int M, int N, int ld, float alpha, float
 int launch_colsum_bf16_scaled(const bf16_t* X, int M, int N, int ld, float alpha, const float* alpha_dev, float* out, hipStream_t s);
 int launch_colsum_f32(const float* X, RowMap rm, int M, int D, float* out, hipStream_t s);
 int launch_token_mean(const float* x, int B, int N, int D, float* out, hipStream_t s);
+int launch_token_mean_bwd(const float* dmean, int B, int N, int D, float* dx, hipStream_t s);
 int launch_cast_bf16(const float* in, bf16_t* out, size_t n, hipStream_t s);
 int launch_gather_rows_bf16(const float* in, RowMap rm, bf16_t* out, int M, int D, hipStream_t s);
 int launch_mask_index(const uint8_t* mask, int B, int L, int nvis, int nmask, int* vis_idx, int* msk_idx, int* status, hipStream_t s);
-int launch_gather_patches(const float* clip, const int* vis_idx, bf16_t* A, int B, int nvis, PatchGeom pg, hipStream_t s);
-int launch_labels(const float* clip, const int* msk_idx, float* labels, int B, int nmask, PatchGeom pg, int norm_pix, hipStream_t s);
+int launch_gather_patches(PixelSrc clip, const int* vis_idx, bf16_t* A, int B, int nvis, PatchGeom pg, hipStream_t s);
+int launch_labels(PixelSrc clip, const int* msk_idx, float* labels, int B, int nmask, PatchGeom pg, int norm_pix, hipStream_t s);
 int launch_fill_masked(float* xfull, const float* mask_token, const float* pos, const int* msk_idx, int B, int L, int nvis,
                        int nmask, int D, hipStream_t s);
 int launch_sgd_step(float* p, float* g, float* buf, size_t n, float lr, float momentum, float dampening, float wd, int nesterov,
                     int first, int maximize, const float* grad_scale, const float* found_inf, int write_grad, hipStream_t s);
+int launch_adam_prep(float* state, double lr, double beta1, double beta2, const float* found_inf, hipStream_t s);
+int launch_adam_step(float* p, float* g, float* m, float* v, size_t n, double lr, double beta1, double beta2, double eps, double wd,
+                     int decoupled, int maximize, const float* state, const float* grad_scale, const float* found_inf, int write_grad,
+                     hipStream_t s);
 int launch_row_normalize(const float* f, bf16_t* fn, float* inv, int n, int p, float eps, hipStream_t s);
 int launch_row_normalize_bwd(const float* f, const float* inv, const float* dfn, float* df, int n, int p, hipStream_t s);
 int launch_nce_finalize(const float* partial, int ntiles, float inv_t, double npos, float* loss, float* stats, hipStream_t s);

@@ -217,6 +217,19 @@ __global__ __launch_bounds__(256) void token_mean_kernel(const float* __restrict
     }
 }
 
+// dx[b][m][d] = dmean[b][d] / N   (backward of token_mean); one f32x4 per thread
+__global__ void token_mean_bwd_kernel(const float* __restrict__ dmean, float* __restrict__ dx, int N, int D, size_t total4) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total4) return;
+    const size_t e = i * 4;
+    const int d = (int)(e % D);
+    const size_t b = e / ((size_t)N * D);
+    f32x4 g = *reinterpret_cast<const f32x4*>(dmean + b * D + d);
+    const float inv = 1.f / (float)N;
+    g *= inv;
+    *reinterpret_cast<f32x4*>(dx + e) = g;
+}
+
 // ============================================================================ elementwise
 __global__ void cast_f32_bf16_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, size_t n) {
     const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 8;
@@ -259,9 +272,20 @@ __global__ void mask_index_kernel(const uint8_t* __restrict__ mask, int L, int n
     if (lane == 0 && (nv != nvis || nm != nmask)) atomicOr(status, 1);
 }
 
+// four consecutive pixels of channel c starting at element `src` (a multiple of 4)
+__device__ __forceinline__ f32x4 load_pixels4(const PixelSrc& px, size_t src, int c) {
+    if (!px.is_u8) return *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(px.ptr) + src);
+    const uint32_t w = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(px.ptr) + src);
+    const float mu = px.mean[c & 3], sd = px.stdv[c & 3];
+    f32x4 v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = ((float)((w >> (8 * j)) & 0xffu) / 255.f - mu) / sd;
+    return v;
+}
+
 // ============================================================================ tube-patch gather (visible tokens only)
 // A[m][k], k = ((c*ts + dt)*ps + dy)*ps + dx  (Conv3d weight order, HF:157-162), clip f32 [B][T][C][H][W]
-__global__ void gather_patches_kernel(const float* __restrict__ clip, const int* __restrict__ vis_idx, bf16_t* __restrict__ A,
+__global__ void gather_patches_kernel(const PixelSrc clip, const int* __restrict__ vis_idx, bf16_t* __restrict__ A,
                                       int B, int nvis, PatchGeom pg) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int K = pg.C * pg.ts * pg.ps * pg.ps;
@@ -274,8 +298,8 @@ __global__ void gather_patches_kernel(const float* __restrict__ clip, const int*
     const int wp = pg.W / pg.ps, hp = pg.H / pg.ps;
     const int tp = tok / (hp * wp), yp = (tok / wp) % hp, xp = tok % wp;
     const size_t src = ((((size_t)b * pg.T + tp * pg.ts + dt) * pg.C + c) * pg.H + yp * pg.ps + dy) * pg.W + xp * pg.ps + dx;
-    const f32x4 a = *reinterpret_cast<const f32x4*>(clip + src);
-    const f32x4 d = *reinterpret_cast<const f32x4*>(clip + src + 4);
+    const f32x4 a = load_pixels4(clip, src, c);
+    const f32x4 d = load_pixels4(clip, src + 4, c);
     *reinterpret_cast<uint4*>(A + (size_t)m * K + k) =
         uint4{pack2bf(a[0], a[1]), pack2bf(a[2], a[3]), pack2bf(d[0], d[1]), pack2bf(d[2], d[3])};
 }
@@ -283,7 +307,7 @@ __global__ void gather_patches_kernel(const float* __restrict__ clip, const int*
 // ============================================================================ pixel targets (HF:588-661)
 // one workgroup per masked token: un-normalise, per-channel mean / unbiased variance over ts*ps*ps
 // values, labels[(dt,dy,dx,c)] = (f - mean) / (sqrt(var) + 1e-6)
-__global__ __launch_bounds__(256) void labels_kernel(const float* __restrict__ clip, const int* __restrict__ msk_idx,
+__global__ __launch_bounds__(256) void labels_kernel(const PixelSrc clip, const int* __restrict__ msk_idx,
                                                      float* __restrict__ labels, int nmask, PatchGeom pg, int norm_pix) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* buf = reinterpret_cast<float*>(smem);   // [C][E]
@@ -298,7 +322,7 @@ __global__ __launch_bounds__(256) void labels_kernel(const float* __restrict__ c
         const int c = i / e4n, e = (i % e4n) * 4;
         const int dx = e % pg.ps, dy = (e / pg.ps) % pg.ps, dt = e / (pg.ps * pg.ps);
         const size_t src = ((((size_t)b * pg.T + tp * pg.ts + dt) * C + c) * pg.H + yp * pg.ps + dy) * pg.W + xp * pg.ps + dx;
-        f32x4 v = *reinterpret_cast<const f32x4*>(clip + src);
+        f32x4 v = load_pixels4(clip, src, c);
         if (C == 3) v = v * std3[c] + mean3[c];
         *reinterpret_cast<f32x4*>(buf + c * E + e) = v;
     }
@@ -572,6 +596,66 @@ __global__ void sgd_step_kernel(float* __restrict__ p, float* __restrict__ g, fl
     }
 }
 
+// torch.optim.Adam / AdamW (pretrain_videomae.py:190-193: AdamW(betas=(0.9, 0.95)) / Adam) over a flat range.
+// adam_prep: state[0] = step count (f32, advanced unless *found_inf != 0), state[1] = lr / (1 - beta1^step),
+// state[2] = sqrt(1 - beta2^step) - the scalars torch derives in double on the host, derived in double here
+__global__ void adam_prep_kernel(float* __restrict__ state, double lr, double beta1, double beta2, const float* __restrict__ found_inf) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (found_inf && *found_inf != 0.f) return;
+    const double step = (double)state[0] + 1.0;
+    state[0] = (float)step;
+    state[1] = (float)(lr / (1.0 - pow(beta1, step)));
+    state[2] = (float)sqrt(1.0 - pow(beta2, step));
+}
+
+//   g = grad / grad_scale;  AdamW: p *= 1 - lr wd;  Adam: g += wd p;  m += (g - m)(1 - b1);  v = b2 v + (1 - b2) g^2;
+//   p -= (lr / bc1) * m / (sqrt(v) / sqrt(bc2) + eps)            (torch/optim/adam.py _single_tensor_adam, same operation order)
+__global__ void adam_step_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                 size_t n, float omb1, float beta2, float omb2, float eps, float wd, float decay_mul, int decoupled,
+                                 int maximize, const float* __restrict__ state, const float* __restrict__ grad_scale,
+                                 const float* __restrict__ found_inf, int write_grad) {
+    if (found_inf && *found_inf != 0.f) return;
+    const float inv = grad_scale ? 1.f / *grad_scale : 1.f;
+    const float step_size = state[1], bc2s = state[2];
+    const size_t i0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i0 >= n) return;
+    const bool vec = i0 + 4 <= n;
+    float pv[4], gv[4], mv[4], vv[4];
+    const int cnt = vec ? 4 : (int)(n - i0);
+    if (vec) {
+        *reinterpret_cast<f32x4*>(pv) = *reinterpret_cast<const f32x4*>(p + i0);
+        *reinterpret_cast<f32x4*>(gv) = *reinterpret_cast<const f32x4*>(g + i0);
+        *reinterpret_cast<f32x4*>(mv) = *reinterpret_cast<const f32x4*>(m + i0);
+        *reinterpret_cast<f32x4*>(vv) = *reinterpret_cast<const f32x4*>(v + i0);
+    } else {
+        for (int e = 0; e < cnt; ++e) { pv[e] = p[i0 + e]; gv[e] = g[i0 + e]; mv[e] = m[i0 + e]; vv[e] = v[i0 + e]; }
+    }
+    float gu[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float gr = gv[e] * inv;
+        if (maximize) gr = -gr;
+        gu[e] = gr;
+        float pe = pv[e];
+        if (wd != 0.f) {
+            if (decoupled) pe *= decay_mul; else gr += wd * pe;
+        }
+        const float me = mv[e] + omb1 * (gr - mv[e]);
+        const float ve = vv[e] * beta2 + omb2 * (gr * gr);
+        const float denom = sqrtf(ve) / bc2s + eps;
+        pv[e] = pe - step_size * (me / denom);
+        mv[e] = me; vv[e] = ve;
+    }
+    if (vec) {
+        *reinterpret_cast<f32x4*>(p + i0) = *reinterpret_cast<f32x4*>(pv);
+        *reinterpret_cast<f32x4*>(m + i0) = *reinterpret_cast<f32x4*>(mv);
+        *reinterpret_cast<f32x4*>(v + i0) = *reinterpret_cast<f32x4*>(vv);
+        if (write_grad) *reinterpret_cast<f32x4*>(g + i0) = *reinterpret_cast<f32x4*>(gu);
+    } else {
+        for (int e = 0; e < cnt; ++e) { p[i0 + e] = pv[e]; m[i0 + e] = mv[e]; v[i0 + e] = vv[e]; if (write_grad) g[i0 + e] = gu[e]; }
+    }
+}
+
 // ============================================================================ launchers
 static inline unsigned blocks_for(size_t items, int per = 256) { return (unsigned)((items + per - 1) / per); }
 
@@ -641,6 +725,14 @@ int launch_token_mean(const float* x, int B, int N, int D, float* out, hipStream
     return BVC_OK;
 }
 
+int launch_token_mean_bwd(const float* dmean, int B, int N, int D, float* dx, hipStream_t s) {
+    BVC_REQUIRE(D % 4 == 0, "token_mean_bwd: D must be a multiple of 4");
+    const size_t total4 = (size_t)B * N * D / 4;
+    hipLaunchKernelGGL(token_mean_bwd_kernel, dim3(blocks_for(total4)), dim3(256), 0, s, dmean, dx, N, D, total4);
+    BVC_CHECK_HIP(hipGetLastError());
+    return BVC_OK;
+}
+
 int launch_cast_bf16(const float* in, bf16_t* out, size_t n, hipStream_t s) {
     hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(blocks_for((n + 7) / 8)), dim3(256), 0, s, in, out, n);
     BVC_CHECK_HIP(hipGetLastError());
@@ -659,7 +751,7 @@ int launch_mask_index(const uint8_t* mask, int B, int L, int nvis, int nmask, in
     return BVC_OK;
 }
 
-int launch_gather_patches(const float* clip, const int* vis_idx, bf16_t* A, int B, int nvis, PatchGeom pg, hipStream_t s) {
+int launch_gather_patches(PixelSrc clip, const int* vis_idx, bf16_t* A, int B, int nvis, PatchGeom pg, hipStream_t s) {
     BVC_REQUIRE(pg.ps % 8 == 0 && pg.W % 4 == 0, "gather_patches: patch size must be a multiple of 8");
     const size_t items = (size_t)B * nvis * (pg.C * pg.ts * pg.ps * pg.ps / 8);
     hipLaunchKernelGGL(gather_patches_kernel, dim3(blocks_for(items)), dim3(256), 0, s, clip, vis_idx, A, B, nvis, pg);
@@ -667,7 +759,7 @@ int launch_gather_patches(const float* clip, const int* vis_idx, bf16_t* A, int 
     return BVC_OK;
 }
 
-int launch_labels(const float* clip, const int* msk_idx, float* labels, int B, int nmask, PatchGeom pg, int norm_pix, hipStream_t s) {
+int launch_labels(PixelSrc clip, const int* msk_idx, float* labels, int B, int nmask, PatchGeom pg, int norm_pix, hipStream_t s) {
     BVC_REQUIRE(pg.ps % 4 == 0, "labels: patch size must be a multiple of 4");
     const int E = pg.ts * pg.ps * pg.ps;
     const size_t lds = (size_t)(pg.C * E + 2 * pg.C) * 4;
@@ -762,6 +854,26 @@ int launch_sgd_step(float* p, float* g, float* buf, size_t n, float lr, float mo
     if (n == 0) return BVC_OK;
     hipLaunchKernelGGL(sgd_step_kernel, dim3(blocks_for((n + 3) / 4)), dim3(256), 0, s, p, g, buf, n, lr, momentum, dampening, wd,
                        nesterov, first, maximize, grad_scale, found_inf, write_grad);
+    BVC_CHECK_HIP(hipGetLastError());
+    return BVC_OK;
+}
+
+int launch_adam_prep(float* state, double lr, double beta1, double beta2, const float* found_inf, hipStream_t s) {
+    hipLaunchKernelGGL(adam_prep_kernel, dim3(1), dim3(64), 0, s, state, lr, beta1, beta2, found_inf);
+    BVC_CHECK_HIP(hipGetLastError());
+    return BVC_OK;
+}
+
+int launch_adam_step(float* p, float* g, float* m, float* v, size_t n, double lr, double beta1, double beta2, double eps, double wd,
+                     int decoupled, int maximize, const float* state, const float* grad_scale, const float* found_inf, int write_grad,
+                     hipStream_t s) {
+    BVC_REQUIRE(((uintptr_t)p % 16 == 0) && ((uintptr_t)g % 16 == 0) && ((uintptr_t)m % 16 == 0) && ((uintptr_t)v % 16 == 0),
+                "adam_step: buffers must be 16-byte aligned");
+    if (n == 0) return BVC_OK;
+    // hyper-parameters arrive as doubles (python floats) and are combined in double before the cast, as torch does
+    hipLaunchKernelGGL(adam_step_kernel, dim3(blocks_for((n + 3) / 4)), dim3(256), 0, s, p, g, m, v, n, (float)(1.0 - beta1), (float)beta2,
+                       (float)(1.0 - beta2), (float)eps, (float)wd, (float)(1.0 - lr * wd), decoupled, maximize, state, grad_scale,
+                       found_inf, write_grad);
     BVC_CHECK_HIP(hipGetLastError());
     return BVC_OK;
 }

@@ -120,6 +120,24 @@ void sinusoid(std::vector<float>& out, int n, int d) {   // HF:80-91, float64 th
 
 }  // namespace
 
+namespace {
+int pixel_src(const void* pixels, const bvc_pixel_format* fmt, int channels, PixelSrc* out) {
+    PixelSrc px = pixels_f32((const float*)pixels);
+    if (fmt && fmt->dtype != BVC_PIXELS_F32) {
+        BVC_REQUIRE(fmt->dtype == BVC_PIXELS_U8, "pixel format: dtype %d unknown", fmt->dtype);
+        BVC_REQUIRE(channels <= 4, "pixel format: uint8 input supports at most 4 channels");
+        px.is_u8 = 1;
+        for (int c = 0; c < 4; ++c) {
+            BVC_REQUIRE(fmt->std[c] != 0.f || c >= channels, "pixel format: std[%d] is zero", c);
+            px.mean[c] = fmt->mean[c];
+            px.stdv[c] = c < channels ? fmt->std[c] : 1.f;
+        }
+    }
+    *out = px;
+    return BVC_OK;
+}
+}  // namespace
+
 // ============================================================================ C ABI
 extern "C" {
 
@@ -215,7 +233,14 @@ int bvc_videomae_create(const bvc_videomae_config* cfg, int max_batch, int num_m
 
 int bvc_videomae_forward(bvc_ctx* c, const float* pixels, const uint8_t* mask, int batch, const float* params,
                          float* loss, float* logits, void* stream) {
-    BVC_REQUIRE(c && pixels && mask && params && loss, "forward: null argument");
+    return bvc_videomae_forward_px(c, pixels, nullptr, mask, batch, params, loss, logits, stream);
+}
+
+int bvc_videomae_forward_px(bvc_ctx* c, const void* pixels_any, const bvc_pixel_format* fmt, const uint8_t* mask, int batch,
+                            const float* params, float* loss, float* logits, void* stream) {
+    BVC_REQUIRE(c && pixels_any && mask && params && loss, "forward: null argument");
+    PixelSrc pixels;
+    TRY(pixel_src(pixels_any, fmt, c->cfg.num_channels, &pixels));
     BVC_REQUIRE(batch >= 1 && batch <= c->max_batch, "forward: batch %d outside [1, %d]", batch, c->max_batch);
     hipStream_t st = (hipStream_t)stream;
     const bvc_videomae_config& cf = c->cfg;
@@ -432,7 +457,15 @@ int bvc_videomae_encoder_create(const bvc_videomae_config* cfg, int max_batch, b
 
 int bvc_videomae_encode(bvc_encoder_ctx* c, const float* pixels, int batch, const float* params, const float* fc_norm_w,
                         const float* fc_norm_b, float fc_norm_eps, float* tokens, float* pooled, void* stream) {
-    BVC_REQUIRE(c && pixels && params && (tokens || pooled), "encode: null argument");
+    return bvc_videomae_encode_px(c, pixels, nullptr, batch, params, fc_norm_w, fc_norm_b, fc_norm_eps, tokens, pooled, stream);
+}
+
+int bvc_videomae_encode_px(bvc_encoder_ctx* c, const void* pixels_any, const bvc_pixel_format* fmt, int batch, const float* params,
+                           const float* fc_norm_w, const float* fc_norm_b, float fc_norm_eps, float* tokens, float* pooled,
+                           void* stream) {
+    BVC_REQUIRE(c && pixels_any && params && (tokens || pooled), "encode: null argument");
+    PixelSrc pixels;
+    TRY(pixel_src(pixels_any, fmt, c->cfg.num_channels, &pixels));
     BVC_REQUIRE(batch >= 1 && batch <= c->max_batch, "encode: batch %d outside [1, %d]", batch, c->max_batch);
     BVC_REQUIRE((fc_norm_w == nullptr) == (fc_norm_b == nullptr), "encode: fc_norm weight and bias go together");
     hipStream_t st = (hipStream_t)stream;
@@ -510,6 +543,17 @@ int bvc_op_sgd_step(float* params, float* grads, float* momentum_buf, int64_t n,
     return launch_sgd_step(params, grads, momentum_buf, (size_t)n, lr, momentum, dampening, weight_decay, nesterov, first_step,
                            maximize, grad_scale, found_inf, write_unscaled_grads, (hipStream_t)stream);
 }
+int bvc_op_adam_prepare(float* state3, double lr, double beta1, double beta2, const float* found_inf, void* stream) {
+    BVC_REQUIRE(state3, "op_adam_prepare: null state");
+    return launch_adam_prep(state3, lr, beta1, beta2, found_inf, (hipStream_t)stream);
+}
+int bvc_op_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, double lr, double beta1, double beta2,
+                     double eps, double weight_decay, int decoupled, int maximize, const float* state3, const float* grad_scale,
+                     const float* found_inf, int write_unscaled_grads, void* stream) {
+    BVC_REQUIRE(params && grads && exp_avg && exp_avg_sq && state3 && n >= 0, "op_adam_step: bad argument");
+    return launch_adam_step(params, grads, exp_avg, exp_avg_sq, (size_t)n, lr, beta1, beta2, eps, weight_decay, decoupled, maximize,
+                            state3, grad_scale, found_inf, write_unscaled_grads, (hipStream_t)stream);
+}
 int bvc_op_row_normalize(const float* f, void* fn_bf16, float* inv_norm, int n, int p, float eps, void* stream) {
     BVC_REQUIRE(f && fn_bf16 && inv_norm, "op_row_normalize: null argument");
     return launch_row_normalize(f, (bf16_t*)fn_bf16, inv_norm, n, p, eps, (hipStream_t)stream);
@@ -533,12 +577,12 @@ int bvc_op_mask_index(const uint8_t* mask, int B, int L, int nvis, int nmask, in
 int bvc_op_gather_patches(const float* clip, const int* vis_idx, void* A, int B, int nvis, int T, int C, int H, int W, int ts,
                           int ps, void* stream) {
     BVC_REQUIRE(clip && vis_idx && A, "op_gather_patches: null argument");
-    return launch_gather_patches(clip, vis_idx, (bf16_t*)A, B, nvis, PatchGeom{T, C, H, W, ts, ps}, (hipStream_t)stream);
+    return launch_gather_patches(pixels_f32(clip), vis_idx, (bf16_t*)A, B, nvis, PatchGeom{T, C, H, W, ts, ps}, (hipStream_t)stream);
 }
 int bvc_op_pixel_labels(const float* clip, const int* msk_idx, float* labels, int B, int nmask, int T, int C, int H, int W, int ts,
                         int ps, int norm_pix, void* stream) {
     BVC_REQUIRE(clip && msk_idx && labels, "op_pixel_labels: null argument");
-    return launch_labels(clip, msk_idx, labels, B, nmask, PatchGeom{T, C, H, W, ts, ps}, norm_pix, (hipStream_t)stream);
+    return launch_labels(pixels_f32(clip), msk_idx, labels, B, nmask, PatchGeom{T, C, H, W, ts, ps}, norm_pix, (hipStream_t)stream);
 }
 
 }  // extern "C"

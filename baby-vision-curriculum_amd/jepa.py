@@ -138,6 +138,7 @@ class VisionTransformer(FlatParamModule):
         self._init_flat(layout, numel, init, frozen=("pos_embed",))
         self._modules["patch_embed"].num_patches = self._pe_info.num_patches
         self._ctx, self._ctx_key = None, None
+        self.pixel_mean, self.pixel_std = 0.5, 0.25      # normalisation applied on the GPU when the input is uint8 frames
 
     @property
     def num_patches(self):
@@ -169,8 +170,10 @@ class VisionTransformer(FlatParamModule):
         N = idx.shape[1] if idx is not None else self.num_patches
         h = self._get_ctx(B)
         out = torch.empty((B, N, self.embed_dim), dtype=torch.float32, device=imgs.device)
-        _lib.check(_lib.lib().bvc_vit_forward(h, imgs.data_ptr(), idx.data_ptr() if idx is not None else None, B, N,
-                                              self._flat.data_ptr(), out.data_ptr(), _lib.current_stream_ptr()), "bvc_vit_forward")
+        fmt = _lib.pixel_format(imgs, self.pixel_mean, self.pixel_std, self.in_chans)
+        _lib.check(_lib.lib().bvc_vit_forward_px(h, imgs.data_ptr(), ctypes.byref(fmt) if fmt is not None else None,
+                                                 idx.data_ptr() if idx is not None else None, B, N, self._flat.data_ptr(),
+                                                 out.data_ptr(), _lib.current_stream_ptr()), "bvc_vit_forward")
         self._live = (imgs, idx)
         return out
 
@@ -197,7 +200,8 @@ class VisionTransformer(FlatParamModule):
                 raise NotImplementedError("one context mask per call (the reference's collator uses nenc=1)")
             idx = _as_idx(masks[0], x.device)
         self._ensure_flat(x.device)
-        imgs = x.detach().to(torch.float32).contiguous()
+        imgs = x.detach()
+        imgs = (imgs if imgs.dtype == torch.uint8 else imgs.to(torch.float32)).contiguous()    # uint8: normalised on the GPU
         anchor = self._param("norm.weight")
         if torch.is_grad_enabled() and anchor.requires_grad:
             return _EncFn.apply(anchor, self, imgs, idx)
@@ -410,3 +414,30 @@ def ema_update(encoder, target_encoder, m):
     """pretrain_jepa.py:431-432 over the flat buffers: one kernel instead of a Python loop over 150 tensors."""
     q, k = encoder.flat_parameters(), target_encoder.flat_parameters()
     _lib.check(_lib.lib().bvc_op_ema(k.data_ptr(), q.data_ptr(), k.numel(), float(m), _lib.current_stream_ptr()), "bvc_op_ema")
+
+
+class _TokenMean(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        B, N, D = x.shape
+        xf = x.detach().to(torch.float32).contiguous()
+        out = torch.empty((B, D), dtype=torch.float32, device=x.device)
+        _lib.check(_lib.lib().bvc_op_token_mean(xf.data_ptr(), B, N, D, out.data_ptr(), _lib.current_stream_ptr()), "bvc_op_token_mean")
+        ctx.shape = (B, N, D)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        B, N, D = ctx.shape
+        gf = g.detach().to(torch.float32).contiguous()
+        dx = torch.empty((B, N, D), dtype=torch.float32, device=g.device)
+        _lib.check(_lib.lib().bvc_op_token_mean_bwd(gf.data_ptr(), B, N, D, dx.data_ptr(), _lib.current_stream_ptr()),
+                   "bvc_op_token_mean_bwd")
+        return dx
+
+
+def token_mean(x):
+    """`x.mean(1)` over the token axis of (B, N, D) encoder output (benchmarks/compute_embeddings_jepa.py:242), one kernel."""
+    if not x.is_cuda or x.dim() != 3 or x.shape[-1] % 4:
+        raise _lib.BvcError("token_mean needs a CUDA (B, N, D) tensor with D % 4 == 0")
+    return _TokenMean.apply(x)

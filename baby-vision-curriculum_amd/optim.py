@@ -1,4 +1,4 @@
-"""Fused SGD for flat parameter buffers (one HIP launch per contiguous run of parameters).
+"""Fused SGD / Adam / AdamW for flat parameter buffers (one HIP launch per contiguous run of parameters).
 
 Same constructor and update rule as ``torch.optim.SGD`` (the reference builds
 ``torch.optim.SGD(xmodel.parameters(), lr, weight_decay, momentum, nesterov=True)`` at
@@ -111,3 +111,86 @@ class SGD(torch.optim.Optimizer):
         for st in sd["state"].values():
             st.pop("_flat_momentum", None)
         return sd
+
+
+class Adam(torch.optim.Optimizer):
+    """torch.optim.Adam's constructor, update rule and state layout (``step``, ``exp_avg``, ``exp_avg_sq`` per parameter;
+    the reference builds Adam / AdamW(betas=(0.9, 0.95)) at pretrain_videomae.py:190-193), as one HIP launch per contiguous
+    run of parameters.  The step count lives on the device so that a step skipped by GradScaler does not advance it."""
+    _step_supports_amp_scaling = True
+    _decoupled = False
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, amsgrad=False, *, maximize=False):
+        if amsgrad:
+            raise NotImplementedError("amsgrad is not implemented (the reference does not use it)")
+        if lr < 0.0 or eps < 0.0 or weight_decay < 0.0 or not (0.0 <= betas[0] < 1.0 and 0.0 <= betas[1] < 1.0):
+            raise ValueError("invalid hyper-parameter")
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=False, maximize=maximize))
+        self._runs = {}
+
+    _contiguous_runs = staticmethod(SGD._contiguous_runs)
+    _group_runs = SGD._group_runs
+
+    def _run_state(self, run):
+        first = run[0]
+        st = self.state[first]
+        flat = st.get("_flat_adam")
+        n = sum(p.numel() for p in run)
+        if flat is None or flat[0].numel() != n:
+            dev = first.device
+            m, v = torch.zeros(n, dtype=torch.float32, device=dev), torch.zeros(n, dtype=torch.float32, device=dev)
+            state3 = torch.zeros(3, dtype=torch.float32, device=dev)
+            have = all("exp_avg" in self.state[p] for p in run)
+            if have:    # after load_state_dict: adopt the loaded per-parameter state (all parameters share one step count)
+                state3[0] = float(self.state[first]["step"])
+            o = 0
+            for p in run:
+                k = p.numel()
+                if have:
+                    m[o:o + k].copy_(self.state[p]["exp_avg"].reshape(-1))
+                    v[o:o + k].copy_(self.state[p]["exp_avg_sq"].reshape(-1))
+                self.state[p]["exp_avg"], self.state[p]["exp_avg_sq"] = m[o:o + k].view(p.shape), v[o:o + k].view(p.shape)
+                self.state[p]["step"] = state3[0]
+                o += k
+            flat = (m, v, state3)
+            st["_flat_adam"] = flat
+        return flat
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        grad_scale = getattr(self, "grad_scale", None)
+        found_inf = getattr(self, "found_inf", None)
+        gs = grad_scale.data_ptr() if grad_scale is not None else None
+        fi = found_inf.data_ptr() if found_inf is not None else None
+        L = _lib.lib()
+        stream = _lib.current_stream_ptr()
+        for gi, group in enumerate(self.param_groups):
+            b1, b2 = group["betas"]
+            for run in self._group_runs(gi, group):
+                n = sum(p.numel() for p in run)
+                m, v, state3 = self._run_state(run)
+                _lib.check(L.bvc_op_adam_prepare(state3.data_ptr(), float(group["lr"]), float(b1), float(b2), fi, stream),
+                           "bvc_op_adam_prepare")
+                _lib.check(L.bvc_op_adam_step(
+                    run[0].data_ptr(), run[0].grad.data_ptr(), m.data_ptr(), v.data_ptr(), n, float(group["lr"]), float(b1), float(b2),
+                    float(group["eps"]), float(group["weight_decay"]), int(self._decoupled), int(group["maximize"]),
+                    state3.data_ptr(), gs, fi, 1, stream), "bvc_op_adam_step")
+        return loss
+
+    def state_dict(self):
+        sd = super().state_dict()
+        for st in sd["state"].values():
+            st.pop("_flat_adam", None)
+        return sd
+
+
+class AdamW(Adam):
+    """torch.optim.AdamW: decoupled weight decay, default 1e-2."""
+    _decoupled = True
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, amsgrad=False, *, maximize=False):
+        super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=amsgrad, maximize=maximize)

@@ -158,3 +158,30 @@ def _adapt_model_simclr(model, n_features, n_out):
     model.fc = ProjectionHead(n_features, n_out)
     _ = model.float()
     return model
+
+
+class SimCLRViT(nn.Module):
+    """BASELINE config 5 ("SimCLR ViT-B, global batch 4096, embedding all-gather"), assembled from reference parts as
+    SURVEY §8 states, because the reference's own get_model only adapts torchvision ResNets (pretrain_simclr.py:71-84):
+    trunk = the reference's video ViT with one frame (pretraining/predictive/vision_transformer.py VisionTransformer,
+    num_frames=1, tubelet 1), features = mean over tokens, ``fc`` = the SimCLR head of pretrain_simclr.py:71-77.
+    ``forward(x)`` takes the (2B, C, H, W) view the reference's forward_loss builds (:322-324) and returns (2B, p)."""
+
+    def __init__(self, model_name="vit_base", image_size=224, patch_size=16, pred_emb_dim=None):
+        super().__init__()
+        from . import jepa
+        self.trunk = jepa.__dict__[model_name](img_size=[image_size], patch_size=patch_size, num_frames=1, tubelet_size=1)
+        d = self.trunk.embed_dim
+        self.fc = ProjectionHead(d, pred_emb_dim or d)
+
+    def forward(self, x):
+        from . import jepa
+        tokens = self.trunk(x.unsqueeze(1))                      # (2B, N, D)
+        return self.fc(jepa.token_mean(tokens))
+
+
+def global_info_nce_loss(temperature, masks, feats_local):
+    """info_nce_loss over the rows of EVERY rank: AllGather (pretraining/predictive/distributed.py:49-76: forward all_gather + cat,
+    backward all_reduce then own slice) in front of the reference's loss.  `masks` are make_masks(global_batch)."""
+    from .distributed import AllGather
+    return info_nce_loss(temperature, masks, AllGather.apply(feats_local))

@@ -115,6 +115,9 @@ class VideoMAEForPreTraining(FlatParamModule):
         self._ctx_key = None
         self.strict_mask_check = False
         self._nmask_cache = {}
+        # uint8 pixel_values are normalised on the GPU as (u / 255 - mean) / std, the loader's ToTensor + Normalize
+        # (homeview.py:221-230 uses 0.5 / 0.25 for every channel); f32 pixel_values are taken as already normalised
+        self.pixel_mean, self.pixel_std = 0.5, 0.25
 
     # ---- library context
     def _get_ctx(self, batch, nmask):
@@ -152,6 +155,7 @@ class VideoMAEForPreTraining(FlatParamModule):
 
     def _run_forward(self, pixels, mask, want_logits):
         cfg = self.config
+        fmt = _lib.pixel_format(pixels, self.pixel_mean, self.pixel_std, cfg.num_channels)
         B = pixels.shape[0]
         nmask = self._num_masked(mask)
         h = self._get_ctx(B, nmask)
@@ -160,9 +164,9 @@ class VideoMAEForPreTraining(FlatParamModule):
         if want_logits:
             pd = cfg.num_channels * cfg.tubelet_size * cfg.patch_size ** 2
             logits = torch.empty((B, nmask, pd), dtype=torch.float32, device=pixels.device)
-        _lib.check(_lib.lib().bvc_videomae_forward(
-            h, pixels.data_ptr(), mask.data_ptr(), B, self._flat.data_ptr(), loss.data_ptr(),
-            logits.data_ptr() if logits is not None else None, _lib.current_stream_ptr()), "bvc_videomae_forward")
+        _lib.check(_lib.lib().bvc_videomae_forward_px(
+            h, pixels.data_ptr(), ctypes.byref(fmt) if fmt is not None else None, mask.data_ptr(), B, self._flat.data_ptr(),
+            loss.data_ptr(), logits.data_ptr() if logits is not None else None, _lib.current_stream_ptr()), "bvc_videomae_forward")
         self._live = (pixels, mask)   # keep the borrowed inputs alive until backward
         return loss, logits
 
@@ -189,7 +193,8 @@ class VideoMAEForPreTraining(FlatParamModule):
         if tuple(bool_masked_pos.shape) != (B, cfg.seq_length):
             raise ValueError(f"bool_masked_pos must have shape {(B, cfg.seq_length)}")
         self._ensure_flat(pixel_values.device)
-        pixels = pixel_values.detach().to(dtype=torch.float32).contiguous()
+        pixels = pixel_values.detach()
+        pixels = (pixels if pixels.dtype == torch.uint8 else pixels.to(dtype=torch.float32)).contiguous()
         mask = bool_masked_pos.to(device=pixels.device, dtype=torch.bool).contiguous()
         anchor = self._param(self._names[0])
         if torch.is_grad_enabled() and anchor.requires_grad:
@@ -258,6 +263,7 @@ class VideoMAEForVideoClassification(FlatParamModule):
             nn.init.zeros_(self.classifier.bias)
         self._ctx = None
         self._ctx_key = None
+        self.pixel_mean, self.pixel_std = 0.5, 0.25      # for uint8 pixel_values, as in VideoMAEForPreTraining
 
     def _get_ctx(self, batch):
         key = (batch, self._flat.device.index)
@@ -293,14 +299,17 @@ class VideoMAEForVideoClassification(FlatParamModule):
             raise ValueError(f"Input size ({T}x{C}x{H}*{W}) doesn't match model ({cfg.num_frames}x{cfg.num_channels}x{cfg.image_size}*{cfg.image_size}).")
         dev = pixel_values.device
         self._ensure_flat(dev)
-        pixels = pixel_values.detach().to(dtype=torch.float32).contiguous()
+        pixels = pixel_values.detach()
+        pixels = (pixels if pixels.dtype == torch.uint8 else pixels.to(dtype=torch.float32)).contiguous()
+        fmt = _lib.pixel_format(pixels, self.pixel_mean, self.pixel_std, cfg.num_channels)
         h = self._get_ctx(B)
         w = self.fc_norm.weight.detach().to(device=dev, dtype=torch.float32).contiguous()
         b = self.fc_norm.bias.detach().to(device=dev, dtype=torch.float32).contiguous()
         pooled = torch.empty((B, cfg.hidden_size), dtype=torch.float32, device=dev)
         tokens = torch.empty((B, cfg.seq_length, cfg.hidden_size), dtype=torch.float32, device=dev) if output_last_hidden_state else None
-        _lib.check(_lib.lib().bvc_videomae_encode(
-            h, pixels.data_ptr(), B, self._flat.data_ptr(), w.data_ptr(), b.data_ptr(), float(self.fc_norm.eps),
+        _lib.check(_lib.lib().bvc_videomae_encode_px(
+            h, pixels.data_ptr(), ctypes.byref(fmt) if fmt is not None else None, B, self._flat.data_ptr(), w.data_ptr(), b.data_ptr(),
+            float(self.fc_norm.eps),
             tokens.data_ptr() if tokens is not None else None, pooled.data_ptr(), _lib.current_stream_ptr()), "bvc_videomae_encode")
         logits = self.classifier(pooled)
         return ImageClassifierOutput(logits=logits, last_hidden_state=tokens)

@@ -94,9 +94,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=16, help="clips per GPU (16 in the reference's slurm scripts)")
+    ap.add_argument("--batch", type=int, default=64,
+                    help="clips per GPU.  SURVEY 8(d) names 16 (the reference's slurm default), 32 and 64; 64 is the default here "
+                         "because it is the fastest of the three on MI355X (profiles/r01_d_batch_sweep.txt)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--torch-sgd", action="store_true", help="use torch.optim.SGD instead of the fused HIP update")
+    ap.add_argument("--per-step", action="store_true", help="diagnostic: per-step HIP-event and host-enqueue times to stderr")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -108,6 +111,11 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_ddp = world > 1 or bool(os.environ.get("BVC_FORCE_DDP"))   # the env switch exercises the RCCL path on one GPU
+    # A one-GPU box shows 256 logical CPUs but grants a 16-core cgroup quota.  torch's default intra-op pool (one thread per
+    # logical CPU) then spins in every parallel CPU op - here the (B, 1568) mask conversion once B * 1568 passes the 32768-element
+    # grain - burns the quota and gets the whole process throttled for the rest of the 100 ms scheduler period: measured as a
+    # 40-60 ms stall every 3rd-4th step at B >= 24 (1271 vs 2088 clips/s at B = 32, profiles/r01_d_cpu_throttle_diag.txt).
+    torch.set_num_threads(min(8, host_cores()))
     if use_ddp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
@@ -158,12 +166,21 @@ def main():
     fence()
     t0 = time.perf_counter()
     e0.record()
+    marks, host = [e0], []
     for _ in range(args.steps):
+        h0 = time.perf_counter()
         loss = step()
+        host.append(time.perf_counter() - h0)
+        if args.per_step:
+            marks.append(torch.cuda.Event(enable_timing=True))
+            marks[-1].record()
     e1.record()
     fence()
     dt = time.perf_counter() - t0
     gpu_ms = e0.elapsed_time(e1)    # HIP events on the stream every kernel of the step is launched on
+    if args.per_step and rank == 0:
+        print("per-step gpu ms :", " ".join(f"{marks[i].elapsed_time(marks[i + 1]):.2f}" for i in range(args.steps)), file=sys.stderr)
+        print("per-step host ms:", " ".join(f"{1e3 * h:.2f}" for h in host), file=sys.stderr)
     final_loss = float(loss.detach())
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if use_ddp:

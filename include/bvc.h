@@ -82,6 +82,18 @@ int bvc_videomae_forward(bvc_ctx* ctx, const float* pixels_dev, const uint8_t* m
  * pretrain_videomae.py:180-181,312).  Ranges arrive tail-first (decoder head ... patch embed). */
 typedef void (*bvc_bucket_fn)(int64_t offset, int64_t count, void* user);
 
+/* Pixel source of the *_px entry points.  BVC_PIXELS_F32: f32 clips already normalised by the loader (what the reference's
+ * dataloader hands over, homeview.py:218-231).  BVC_PIXELS_U8: the loader's uint8 frames, normalised while they are read as
+ * (u / 255 - mean[c]) / std[c] - ToTensor + Normalize with the same operation order, hence bit-identical values - so that
+ * a quarter of the bytes cross PCIe and HBM (the input side of the step).  NULL format = BVC_PIXELS_F32. */
+enum { BVC_PIXELS_F32 = 0, BVC_PIXELS_U8 = 1 };
+typedef struct bvc_pixel_format {
+    int dtype;
+    float mean[4], std[4]; /* per channel; used for BVC_PIXELS_U8 only */
+} bvc_pixel_format;
+int bvc_videomae_forward_px(bvc_ctx* ctx, const void* pixels_dev, const bvc_pixel_format* fmt, const uint8_t* mask_dev, int batch,
+                            const float* params_dev, float* loss_dev, float* logits_dev, void* stream);
+
 /* Replaces autograd's backward of the step (scaler.scale(loss).backward(), pretrain_videomae.py:312).
  *   grad_loss_dev f32 scalar on the device: d(objective)/d(loss) (GradScaler's scale)
  *   grads_dev     f32 flat gradient buffer, OVERWRITTEN with d(objective)/d(param) */
@@ -111,6 +123,9 @@ void bvc_videomae_encoder_destroy(bvc_encoder_ctx* ctx);
 int bvc_videomae_encode(bvc_encoder_ctx* ctx, const float* pixels_dev, int batch, const float* params_dev,
                         const float* fc_norm_w, const float* fc_norm_b, float fc_norm_eps, float* tokens_dev,
                         float* pooled_dev, void* stream);
+int bvc_videomae_encode_px(bvc_encoder_ctx* ctx, const void* pixels_dev, const bvc_pixel_format* fmt, int batch,
+                           const float* params_dev, const float* fc_norm_w, const float* fc_norm_b, float fc_norm_eps,
+                           float* tokens_dev, float* pooled_dev, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * JEPA encoder and predictor (pretraining/predictive/vision_transformer.py).  Same conventions as above: flat f32
@@ -135,6 +150,8 @@ void bvc_vit_destroy(bvc_vit_ctx* ctx);
  * out f32 [B*ntok][embed_dim] (after the final LayerNorm). */
 int bvc_vit_forward(bvc_vit_ctx* ctx, const float* imgs_dev, const int* idx_dev, int batch, int ntok, const float* params_dev,
                     float* out_dev, void* stream);
+int bvc_vit_forward_px(bvc_vit_ctx* ctx, const void* imgs_dev, const bvc_pixel_format* fmt, const int* idx_dev, int batch, int ntok,
+                       const float* params_dev, float* out_dev, void* stream);
 /* d(out) f32 [B*ntok][embed_dim] -> flat gradients (overwritten); buckets reported tail-first as for VideoMAE. */
 int bvc_vit_backward(bvc_vit_ctx* ctx, const float* dout_dev, float* grads_dev, bvc_bucket_fn on_bucket, void* user, void* stream);
 
@@ -168,6 +185,11 @@ int bvc_op_smooth_l1_fwd(const float* z, const float* h, int64_t n, float* works
 int bvc_op_smooth_l1_bwd(const float* z, const float* h, const float* grad_loss, int64_t n, float* dz, void* stream);
 /* target <- momentum * target + (1 - momentum) * online over a flat range (pretrain_jepa.py:431-432) */
 int bvc_op_ema(float* target, const float* online, int64_t n, float momentum, void* stream);
+/* mean over the tokens of each sample, f32 [batch][ntok][dim] -> [batch][dim], and its backward (dx = dmean / ntok for every
+ * token): `xmodel(inputs).mean(1)` of benchmarks/compute_embeddings_jepa.py:242 and the pooling between a ViT trunk and the
+ * SimCLR head (BASELINE config 5).  Fixed summation order. */
+int bvc_op_token_mean(const float* x, int batch, int ntok, int dim, float* out, void* stream);
+int bvc_op_token_mean_bwd(const float* dmean, int batch, int ntok, int dim, float* dx, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Operator-level entry points (the kernels the step is built from; also used by the parity tests). */
@@ -224,6 +246,14 @@ int bvc_op_nce_finalize(const float* partial, int ntiles, float inv_temperature,
 int bvc_op_sgd_step(float* params, float* grads, float* momentum_buf, int64_t n, float lr, float momentum, float dampening,
                     float weight_decay, int nesterov, int first_step, int maximize, const float* grad_scale,
                     const float* found_inf, int write_unscaled_grads, void* stream);
+/* One-pass torch.optim.AdamW / Adam update over a flat f32 range (pretrain_videomae.py:190-193, pretrain_simclr.py:238-240).
+ * state3 = device {step count, lr / (1 - beta1^step), sqrt(1 - beta2^step)}: bvc_op_adam_prepare advances it once per optimiser
+ * step (not at all when *found_inf != 0), bvc_op_adam_step consumes it.  Hyper-parameters are doubles (python floats) and are
+ * combined in double before the cast to f32, as torch does.  decoupled = 1: AdamW (p *= 1 - lr wd); 0: Adam (g += wd p). */
+int bvc_op_adam_prepare(float* state3, double lr, double beta1, double beta2, const float* found_inf, void* stream);
+int bvc_op_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, double lr, double beta1, double beta2,
+                     double eps, double weight_decay, int decoupled, int maximize, const float* state3, const float* grad_scale,
+                     const float* found_inf, int write_unscaled_grads, void* stream);
 /* boolean mask -> ascending visible / masked token lists (the order x[~mask] / x[mask] produce, HF:121,578-579) */
 int bvc_op_mask_index(const uint8_t* mask, int B, int L, int nvis, int nmask, int* vis_idx, int* msk_idx, int* status, void* stream);
 /* tube patches of the visible tokens in Conv3d weight order (HF:157-177) */

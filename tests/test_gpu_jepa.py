@@ -132,3 +132,17 @@ def test_ema_update_and_training_loop():
     for k, v in tgt.state_dict().items():
         assert G.rel_err(v.cpu(), ref_t[k]) < 1e-5, k
     assert all(l == l for l in losses) and losses[-1] < losses[0]
+
+
+def test_uint8_frames_equal_normalised_f32_bitwise():
+    from oracle import jepa_oracle as jo
+    cfg = jo.TINY
+    enc = bvc.jepa.VisionTransformer(img_size=[cfg.image_size], patch_size=cfg.patch_size, num_frames=cfg.num_frames,
+                                     tubelet_size=cfg.tubelet_size, embed_dim=cfg.embed_dim, depth=cfg.depth,
+                                     num_heads=cfg.num_heads).to(dev)
+    g = torch.Generator().manual_seed(5)
+    u8 = torch.randint(0, 256, (2, cfg.num_frames, cfg.in_chans, cfg.image_size, cfg.image_size), generator=g, dtype=torch.uint8)
+    with torch.no_grad():
+        a = enc(((u8.float() / 255.0 - 0.5) / 0.25).to(dev))
+        b = enc(u8.to(dev))
+    assert torch.equal(a, b)

@@ -442,3 +442,63 @@ def test_fused_sgd_with_gradscaler_skips_on_inf():
             torch.testing.assert_close(gflat, g, rtol=1e-6, atol=1e-6)   # unscaled gradient written back
         torch.cuda.synchronize()
         torch.testing.assert_close(flat, ref, rtol=1e-5, atol=1e-5)
+
+
+# --------------------------------------------------------------------------- fused Adam / AdamW
+@pytest.mark.parametrize("cls,wd,betas", [("AdamW", 0.05, (0.9, 0.95)), ("AdamW", 0.0, (0.9, 0.999)), ("Adam", 0.0, (0.9, 0.999)),
+                                          ("Adam", 1e-3, (0.8, 0.9))])
+def test_fused_adam_matches_torch(cls, wd, betas):
+    """bvc.optim.AdamW / Adam over a flat buffer vs torch.optim (the reference's --optim adamw / adam, pretrain_videomae.py:190-193)."""
+    torch.manual_seed(0)
+    sizes = [(33, 7), (129,), (64, 64), (5,)]
+    n = sum(int(np.prod(s)) for s in sizes)
+    flat = torch.randn(n, device=dev)
+    mine, ref, o = [], [], 0
+    for sz in sizes:
+        k = int(np.prod(sz))
+        mine.append(torch.nn.Parameter(flat[o:o + k].view(sz)))
+        ref.append(torch.nn.Parameter(flat[o:o + k].view(sz).clone()))
+        o += k
+    a = getattr(G.bvc.optim, cls)(mine, lr=3e-3, betas=betas, weight_decay=wd)
+    b = getattr(torch.optim, cls)(ref, lr=3e-3, betas=betas, weight_decay=wd, foreach=False)
+    gflat = torch.empty(n, device=dev)
+    for it in range(4):
+        gflat.copy_(torch.randn(n, device=dev))
+        o = 0
+        for pm, pr in zip(mine, ref):
+            k = pm.numel()
+            pm.grad = gflat[o:o + k].view(pm.shape)
+            pr.grad = gflat[o:o + k].view(pr.shape).clone()
+            o += k
+        a.step()
+        b.step()
+        for pm, pr in zip(mine, ref):
+            assert torch.allclose(pm, pr, rtol=2e-6, atol=2e-7), (it, float((pm - pr).abs().max()))
+    sd = a.state_dict()
+    st0 = sd["state"][0]
+    assert set(st0) == {"step", "exp_avg", "exp_avg_sq"} and float(st0["step"]) == 4.0
+    assert torch.allclose(st0["exp_avg"], b.state[ref[0]]["exp_avg"], rtol=1e-5, atol=1e-7)
+    assert torch.allclose(st0["exp_avg_sq"], b.state[ref[0]]["exp_avg_sq"], rtol=1e-5, atol=1e-9)
+
+
+def test_fused_adamw_with_gradscaler_skips_on_inf():
+    p = torch.nn.Parameter(torch.ones(256, device=dev))
+    opt = G.bvc.optim.AdamW([p], lr=0.1, betas=(0.9, 0.95), weight_decay=0.0)
+    scaler = torch.amp.GradScaler("cuda", init_scale=64.0)
+    loss = (p * 2.0).sum()
+    scaler.scale(loss).backward()
+    scaler.step(opt)
+    scaler.update()
+    torch.cuda.synchronize()
+    # first Adam step moves every weight by lr * sign(g) (bias-corrected m / sqrt(v) = 1); the gradient was unscaled (2, not 128)
+    assert torch.allclose(p.detach(), torch.full_like(p, 0.9), atol=1e-5)
+    assert torch.allclose(p.grad, torch.full_like(p, 2.0))
+    assert float(opt.state[p]["step"]) == 1.0
+    before = p.detach().clone()
+    opt.zero_grad()
+    scaler.scale((p * float("inf")).sum()).backward()
+    scaler.step(opt)
+    scaler.update()
+    torch.cuda.synchronize()
+    assert torch.equal(p.detach(), before) and float(opt.state[p]["step"]) == 1.0     # skipped: nothing moved, step not advanced
+    assert scaler.get_scale() == 32.0

@@ -93,3 +93,57 @@ def test_simclr_step_like_the_reference_loop():
         opt.step()
         losses.append(float(loss))
     assert all(torch.isfinite(torch.tensor(losses))) and losses[-1] < losses[0]
+
+
+def test_simclr_vit_composition_matches_oracle():
+    """BASELINE config 5 composition (the reference's video ViT with one frame as trunk + token mean + SimCLR head +
+    info_nce_loss): loss within 1e-3 of the oracle composition, trunk / head gradients at bf16-operand tolerance."""
+    from oracle import jepa_oracle as jo
+    cfg = jo.JepaConfig(image_size=64, patch_size=16, num_frames=1, embed_dim=128, depth=2, num_heads=2, pred_dim=64, pred_depth=1)
+    B, D = 8, cfg.embed_dim
+    enc_p = jo.make_params(jo.encoder_shapes(cfg), cfg, seed=4)
+    head_p = so.head_params(D, D, seed=9)
+    g = torch.Generator().manual_seed(21)
+    imgs = torch.randn(2 * B, cfg.in_chans, cfg.image_size, cfg.image_size, generator=g)
+
+    ep = {k: v.clone().requires_grad_(k != "pos_embed") for k, v in enc_p.items()}
+    hp = {k: v.clone().requires_grad_(True) for k, v in head_p.items()}
+    tok = jo.encoder_forward(cfg, ep, imgs.unsqueeze(1))
+    feats = so.head_forward(tok.mean(1), hp["0.weight"], hp["0.bias"], hp["2.weight"], hp["2.bias"])
+    ref = so.info_nce_loss(0.1, so.make_masks(B), feats)
+    ref.backward()
+
+    model = bvc.simclr.SimCLRViT.__new__(bvc.simclr.SimCLRViT)
+    torch.nn.Module.__init__(model)
+    model.trunk = bvc.jepa.VisionTransformer(img_size=[cfg.image_size], patch_size=cfg.patch_size, num_frames=1, tubelet_size=1,
+                                             embed_dim=D, depth=cfg.depth, num_heads=cfg.num_heads)
+    model.fc = bvc.simclr.ProjectionHead(D, D)
+    model.trunk.load_state_dict(enc_p)
+    model.fc.load_state_dict(head_p)
+    model.to(dev).train()
+    out = model(imgs.to(dev))
+    assert tuple(out.shape) == (2 * B, D)
+    loss = bvc.simclr.global_info_nce_loss(0.1, bvc.simclr.make_masks(B, dev), out)     # single process: AllGather is the identity
+    loss.backward()
+    torch.cuda.synchronize()
+    assert abs(float(loss) - float(ref)) / abs(float(ref)) < 1e-3, (float(loss), float(ref))
+    assert G.rel_err(out.detach().cpu(), feats.detach()) < 2e-2
+    named = dict(model.trunk.named_parameters())
+    num = sum(float((named[k].grad.cpu() - ep[k].grad).double().pow(2).sum()) for k in ep if ep[k].grad is not None)
+    den = sum(float(ep[k].grad.double().pow(2).sum()) for k in ep if ep[k].grad is not None)
+    assert (num / den) ** 0.5 < 8e-2, (num / den) ** 0.5
+    for k in ("blocks.0.attn.qkv.weight", "blocks.1.mlp.fc2.weight", "patch_embed.proj.weight"):
+        gn, rn = float(named[k].grad.norm()), float(ep[k].grad.norm())
+        assert abs(gn - rn) / rn < 3e-2, (k, gn, rn)
+    hn = dict(model.fc.named_parameters())
+    for k in head_p:
+        assert G.rel_err(hn[k].grad.cpu(), hp[k].grad) < 8e-2, k
+
+
+def test_token_mean_forward_backward():
+    x = torch.randn(5, 37, 192, device=dev, requires_grad=True)
+    y = bvc.jepa.token_mean(x)
+    assert torch.allclose(y, x.detach().mean(1), atol=1e-6)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    assert torch.allclose(x.grad, (gy / 37)[:, None, :].expand_as(x), atol=1e-7)

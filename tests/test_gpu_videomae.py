@@ -289,3 +289,34 @@ def test_embedding_from_pretraining_model_like_adapt_videomae():
         tgt(pixel_values=pixels)          # CPU tensor: no CPU path
     with pytest.raises(ValueError):
         tgt(pixel_values=pixels[:, :2].to(dev))
+
+
+# ------------------------------------------------------------------ uint8 input (the input side of the step)
+def test_uint8_frames_equal_loader_normalised_f32_bitwise():
+    """The loader's uint8 frames normalised on the GPU, (u/255 - 0.5)/0.25 in ToTensor + Normalize's operation order
+    (homeview.py:221-230), must give exactly the step that the f32 clip normalised by torch gives: same loss bits, same grads."""
+    cfg = vo.TINY
+    params = vo.make_params(cfg, seed=0)
+    g = torch.Generator().manual_seed(3)
+    u8 = torch.randint(0, 256, (3, cfg.num_frames, cfg.num_channels, cfg.image_size, cfg.image_size), generator=g, dtype=torch.uint8)
+    f32 = (u8.float() / 255.0 - 0.5) / 0.25
+    _, mask = vo.synthetic_batch(cfg, 3, 0, 0.75)
+    res = []
+    for px in (f32, u8):
+        m = _model(cfg, params)
+        out = m(px.to(dev), bool_masked_pos=mask.to(dev), output_logits=True)
+        out.loss.backward()
+        torch.cuda.synchronize()
+        res.append((out.loss.detach().cpu(), out.logits.cpu(), m.flat_grads().detach().cpu().clone()))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
+    # encoder-only inference and a non-default normalisation
+    kw = {k: v for k, v in cfg.__dict__.items() if k != "decoder_norm_eps"}
+    enc = bvc.VideoMAEForVideoClassification(bvc.VideoMAEConfig(num_labels=0, **kw))
+    enc.load_state_dict({k: v for k, v in params.items() if k.startswith("videomae.")}, strict=False)
+    enc.to(dev).eval()
+    enc.pixel_mean, enc.pixel_std = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
+    mean = torch.tensor(enc.pixel_mean).view(1, 1, 3, 1, 1)
+    std = torch.tensor(enc.pixel_std).view(1, 1, 3, 1, 1)
+    a = enc(pixel_values=((u8.float() / 255.0 - mean) / std).to(dev)).logits
+    b = enc(pixel_values=u8.to(dev)).logits
+    assert torch.equal(a, b)

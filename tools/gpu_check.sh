@@ -27,6 +27,11 @@ for step in "$@"; do
     smoke) run smoke 200 python -c "import __graft_entry__ as g; g.smoke()" ;;
     bench) run bench 400 python bench.py ;;
     bench32) run bench32 400 python bench.py --batch 32 --no-cpu-baseline ;;
+    diag32) run diag32 300 python bench.py --batch 32 --no-cpu-baseline --per-step
+            OMP_NUM_THREADS=4 run diag32omp 300 python bench.py --batch 32 --no-cpu-baseline --per-step
+            run diag24 300 python bench.py --batch 24 --no-cpu-baseline --per-step
+            run diag48 300 python bench.py --batch 48 --no-cpu-baseline --per-step ;;
+    sweepb) for b in 16 32 48 64 96 128; do run bench_b$b 300 python bench.py --batch $b --no-cpu-baseline --steps 20; done ;;
     bench64) run bench64 400 python bench.py --batch 64 --no-cpu-baseline --steps 15 ;;
     benchq) run benchq 300 python bench.py --no-cpu-baseline ;;
     benchddp) BVC_FORCE_DDP=1 run benchddp 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --steps 20 --warmup 3 --no-cpu-baseline ;;

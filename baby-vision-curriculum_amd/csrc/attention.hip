@@ -530,10 +530,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const bf16_t* __r
 static int xcd_remap() { return getenv("BVC_ATTN_PLAIN_GRID") == nullptr; }
 
 template <int HD>
-static int fwd_hd(const bf16_t* qkv, bf16_t* ctx, float* lse, int B, int N, int H, hipStream_t stream) {
+static int fwd_hd(const bf16_t* qkv, bf16_t* ctx, float* lse, int B, int N, int H, hipStream_t stream, float sm_scale) {
     const int D = H * HD;
     const size_t bytes = (size_t)B * N * 3 * D * 2;
-    const float scale_log2 = (1.0f / sqrtf((float)HD)) * 1.4426950408889634f;
+    const float scale_log2 = (sm_scale > 0.f ? sm_scale : 1.0f / sqrtf((float)HD)) * 1.4426950408889634f;
     const dim3 grid((unsigned)(((N + 127) / 128) * B * H));
     hipLaunchKernelGGL(attn_fwd_kernel<HD>, grid, dim3(256), 4 * 64 * HD * 2, stream, qkv, ctx, lse, N, H, D, (uint32_t)bytes, scale_log2,
                        xcd_remap());
@@ -543,10 +543,10 @@ static int fwd_hd(const bf16_t* qkv, bf16_t* ctx, float* lse, int B, int N, int 
 
 template <int HD>
 static int bwd_hd(const bf16_t* qkv, const bf16_t* ctx, const bf16_t* dctx, const float* lse, float* delta, bf16_t* dqkv, int B,
-                  int N, int H, hipStream_t stream) {
+                  int N, int H, hipStream_t stream, float sm_scale) {
     const int D = H * HD;
     const size_t bytes = (size_t)B * N * 3 * D * 2;
-    const float scale = 1.0f / sqrtf((float)HD), scale_log2 = scale * 1.4426950408889634f;
+    const float scale = sm_scale > 0.f ? sm_scale : 1.0f / sqrtf((float)HD), scale_log2 = scale * 1.4426950408889634f;
     {
         const long long total = (long long)B * N * H * (HD / 8);
         hipLaunchKernelGGL(attn_delta_kernel<HD>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, dctx, ctx, delta, B, N, H, D);
@@ -561,20 +561,20 @@ static int bwd_hd(const bf16_t* qkv, const bf16_t* ctx, const bf16_t* dctx, cons
     return BVC_OK;
 }
 
-int launch_attn_fwd(const bf16_t* qkv, bf16_t* ctx, float* lse, int B, int N, int H, int head_dim, hipStream_t stream) {
+int launch_attn_fwd(const bf16_t* qkv, bf16_t* ctx, float* lse, int B, int N, int H, int head_dim, hipStream_t stream, float sm_scale) {
     BVC_REQUIRE(B > 0 && N > 0 && H > 0, "attn_fwd: empty shape");
     BVC_REQUIRE(head_dim == 64 || head_dim == 32, "attn_fwd: head_dim %d unsupported (32 or 64)", head_dim);
     BVC_REQUIRE((size_t)B * N * 3 * H * head_dim * 2 < 0xffffffffull, "attn_fwd: qkv larger than 4 GiB");
-    return head_dim == 64 ? fwd_hd<64>(qkv, ctx, lse, B, N, H, stream) : fwd_hd<32>(qkv, ctx, lse, B, N, H, stream);
+    return head_dim == 64 ? fwd_hd<64>(qkv, ctx, lse, B, N, H, stream, sm_scale) : fwd_hd<32>(qkv, ctx, lse, B, N, H, stream, sm_scale);
 }
 
 int launch_attn_bwd(const bf16_t* qkv, const bf16_t* ctx, const bf16_t* dctx, const float* lse, float* delta,
-                    bf16_t* dqkv, int B, int N, int H, int head_dim, hipStream_t stream) {
+                    bf16_t* dqkv, int B, int N, int H, int head_dim, hipStream_t stream, float sm_scale) {
     BVC_REQUIRE(B > 0 && N > 0 && H > 0, "attn_bwd: empty shape");
     BVC_REQUIRE(head_dim == 64 || head_dim == 32, "attn_bwd: head_dim %d unsupported (32 or 64)", head_dim);
     BVC_REQUIRE((size_t)B * N * 3 * H * head_dim * 2 < 0xffffffffull, "attn_bwd: qkv larger than 4 GiB");
-    return head_dim == 64 ? bwd_hd<64>(qkv, ctx, dctx, lse, delta, dqkv, B, N, H, stream)
-                          : bwd_hd<32>(qkv, ctx, dctx, lse, delta, dqkv, B, N, H, stream);
+    return head_dim == 64 ? bwd_hd<64>(qkv, ctx, dctx, lse, delta, dqkv, B, N, H, stream, sm_scale)
+                          : bwd_hd<32>(qkv, ctx, dctx, lse, delta, dqkv, B, N, H, stream, sm_scale);
 }
 
 }  // namespace bvc

@@ -17,6 +17,8 @@
 //     contiguous run of tiles, consecutive tiles share the A row panel.
 //   * up to 4 independent problems per launch (grouped GEMM) to fill 256 CUs with the small
 //     weight-gradient products of one transformer layer.
+#include <stdlib.h>
+
 #include "gemm.h"
 
 namespace bvc {
@@ -26,6 +28,7 @@ namespace bvc {
 struct GemmGroup {
     int nprob;
     int tile_start[kMaxGroup + 1];
+    int panel[kMaxGroup];          // column tiles per panel of the tile walk (0 = the legacy walk, A/B only); see pick_panel
     GemmProblem prob[kMaxGroup];
 };
 
@@ -120,14 +123,37 @@ __global__ __launch_bounds__(256, LB) void gemm_kernel(const GemmGroup g) {
         if (i < g.nprob && lid >= g.tile_start[i]) pi = i;
     const GemmProblem& p = g.prob[pi];
     lid -= g.tile_start[pi];
-    const int split = lid % p.split_k;
-    const int tile = lid / p.split_k;
-    // Tiles are walked along the SHORTER side of the tile grid first, so the contiguous run of tiles an XCD owns covers whole
-    // short lines: its L2 then fetches few distinct operand slabs (dec fc2 dW, 3 x 12 tiles: 7.5 slabs per 13.5 tiles instead
-    // of 14; profiles/r01_d_traffic_b16_dispatches.txt showed 552 MB fetched per decoder dW launch against 289 MB of operands).
+    // Tile walk inside one problem.  An XCD runs a contiguous run of ids, ~64 of them at a time (32 CUs x 2 workgroups), and
+    // whatever those 64 workgroups share must fit its 4 MiB L2:
+    //   * K-splits are the SLOWEST index: the workgroups resident together then belong to one split and differ in (m, n), so
+    //     they share operand slabs (with the split fastest, 4 of every 4 neighbours shared nothing);
+    //   * columns are walked in panels of `panel` tiles, rows fastest-but-one: 64 neighbours form a rows x panel block whose
+    //     B panel stays in L2 while the rows stream past it.  Measured before this walk (profiles/r01_d_traffic_b64_dispatches.txt):
+    //     encoder fc1 at B=64 fetched 259 MB for 20 MB of operands - its 4.7 MB weight cycled through L2 once per row group.
     const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
-    const bool m_fast = tiles_n > tiles_m;
-    const int m0 = (m_fast ? tile % tiles_m : tile / tiles_n) * BM, n0 = (m_fast ? tile / tiles_m : tile % tiles_n) * BN;
+    const int ntiles = tiles_m * tiles_n;
+    int split, tm, tn;
+    const int G = g.panel[pi];
+    if (G > 0) {
+        split = lid / ntiles;
+        const int t = lid - split * ntiles;
+        const int full = (tiles_n / G) * G * tiles_m;          // tiles in the full-width panels
+        if (t < full) {
+            const int pn = t / (G * tiles_m), w = t - pn * G * tiles_m;
+            tm = w / G; tn = pn * G + (w - tm * G);
+        } else {
+            const int r = tiles_n % G, w = t - full;
+            tm = w / r; tn = (tiles_n - r) + (w - tm * r);
+        }
+    } else {   // legacy walk: split fastest, then along the shorter side of the tile grid
+        split = lid % p.split_k;
+        const int tl = lid / p.split_k;
+        const bool m_fast = tiles_n > tiles_m;
+        tm = m_fast ? tl % tiles_m : tl / tiles_n;
+        tn = m_fast ? tl / tiles_m : tl % tiles_n;
+    }
+    const int tile = tm * tiles_n + tn;     // id for the per-tile loss partials (independent of the walk)
+    const int m0 = tm * BM, n0 = tn * BN;
 
     const int nt_all = (p.K + BK - 1) / BK;
     const int per = (nt_all + p.split_k - 1) / p.split_k;
@@ -475,6 +501,31 @@ int gemm_pick_tile(const GemmProblem* probs, int nprob, int tile_cfg) {
     return 2;
 }
 
+// Column tiles per panel for the kernel's tile walk (see gemm_kernel).  Model: an XCD owns rows_x = tiles_m / 8 tile rows of
+// the problem; with panels of G column tiles the A rows are fetched once per panel, and the B panel is fetched once if it fits
+// ~2 MiB of the L2 and otherwise once per resident wave of 64 workgroups.  Candidates: no panels, or the widest panel that fits.
+static int pick_panel(const GemmProblem& p, int cfg, GemmLayout layout) {
+    if (getenv("BVC_GEMM_LEGACY_WALK") != nullptr) return 0;     // read per launch: same-process A/B (tools/microbench.py)
+    (void)layout;
+    int bm, bn;
+    tile_dims(cfg, bm, bn);
+    const int tiles_m = (p.M + bm - 1) / bm, tiles_n = (p.N + bn - 1) / bn;
+    const double kper = (double)((p.K + p.split_k - 1) / p.split_k);
+    const double a_slab = bm * kper * 2.0, b_slab = bn * kper * 2.0, cap = 2.0 * 1024 * 1024;
+    const double rows_x = tiles_m / 8.0 > 1.0 ? tiles_m / 8.0 : 1.0;
+    auto cost = [&](int G) {
+        const double npan = (double)((tiles_n + G - 1) / G);
+        const double waves = rows_x * G / 64.0 > 1.0 ? rows_x * G / 64.0 : 1.0;
+        return rows_x * a_slab * npan + tiles_n * b_slab * (G * b_slab <= cap ? 1.0 : waves);
+    };
+    int gmax = (int)(cap / b_slab);
+    if (gmax < 1) gmax = 1;
+    if (gmax >= tiles_n) return tiles_n;
+    const int npan = (tiles_n + gmax - 1) / gmax;
+    const int G = (tiles_n + npan - 1) / npan;
+    return cost(G) < cost(tiles_n) ? G : tiles_n;
+}
+
 int gemm_num_tiles(const GemmProblem& p, int tile_cfg) { return tiles_for(p, gemm_pick_tile(&p, 1, tile_cfg)); }
 
 template <int BM, int BN, bool AT, bool BT, int NS, int LB = 2, bool EARLY = true>
@@ -537,11 +588,12 @@ int launch_gemm(const GemmProblem* probs, int nprob, GemmLayout layout, int tile
             BVC_REQUIRE(p.epi == EPI_F32 || (p.epi == EPI_RESID && p.resid == p.C),
                         "launch_gemm: split_k needs an accumulating f32 epilogue");
         g.prob[i] = p;
+        g.panel[i] = pick_panel(p, cfg, layout);
         g.tile_start[i] = total;
         total += tiles_for(p, cfg) * p.split_k;
     }
     g.tile_start[nprob] = total;
-    for (int i = nprob; i < kMaxGroup; ++i) { g.prob[i] = probs[0]; g.tile_start[i + 1] = total; }
+    for (int i = nprob; i < kMaxGroup; ++i) { g.prob[i] = probs[0]; g.panel[i] = g.panel[0]; g.tile_start[i + 1] = total; }
     int kmax = 0;
     for (int i = 0; i < nprob; ++i) kmax = probs[i].K > kmax ? probs[i].K : kmax;
     const int ns = gemm_pick_stages(cfg, layout, kmax, stages);

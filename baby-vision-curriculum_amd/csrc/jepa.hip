@@ -9,6 +9,8 @@
 // all tokens and gathers afterwards, :383-391); q,k,v are the reference's own fused qkv Linear; index lists are int32.
 #include <math.h>
 #include <stdio.h>
+
+#include <algorithm>
 #include <string.h>
 
 #include "stack.h"
@@ -63,7 +65,7 @@ int check_pred(const bvc_predictor_config& c) {
     BVC_REQUIRE(c.seq_len > 0 && c.depth >= 1 && c.num_heads > 0, "predictor config: bad sizes");
     BVC_REQUIRE(c.pred_dim % c.num_heads == 0, "predictor config: pred_dim %% num_heads != 0");
     const int hd = c.pred_dim / c.num_heads;
-    BVC_REQUIRE(hd == 64 || hd == 32, "predictor config: head_dim %d unsupported (32 or 64; ViT-L's 24 is not built yet)", hd);
+    BVC_REQUIRE(hd % 8 == 0 && hd <= 64, "predictor config: head_dim %d unsupported (multiples of 8 up to 64; 24 runs zero-padded to 32)", hd);
     BVC_REQUIRE(c.embed_dim % 64 == 0 && c.pred_dim % 64 == 0 && c.mlp_hidden % 64 == 0, "predictor config: widths must be multiples of 64");
     BVC_REQUIRE(c.embed_dim <= 1024 && c.pred_dim <= 1024, "predictor config: widths above 1024 unsupported");
     return BVC_OK;
@@ -313,7 +315,8 @@ int bvc_predictor_create(const bvc_predictor_config* cfg, int max_batch, int max
     A(c->arena.alloc(&c->dout_bf, M * D));
     A(c->arena.alloc(&c->dres, M * Dp));
     A(c->arena.alloc(&c->dxe, Mc * Dp));
-    A(alloc_work(c->arena, c->w, M * Dp, M * I, S * H * max_tokens, ln_bwd_workspace_floats_upto((int)M, Dp)));
+    // dctx / dqkv scratch is as wide as the (possibly zero-padded) attention rows: Da = H * 32 when the heads are 24 wide
+    A(alloc_work(c->arena, c->w, M * (size_t)std::max(Dp, c->st.Da), M * I, S * H * max_tokens, ln_bwd_workspace_floats_upto((int)M, Dp)));
 #undef A
     *out = c;
     return BVC_OK;

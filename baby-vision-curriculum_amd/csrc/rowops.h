@@ -48,6 +48,10 @@ int launch_adam_prep(float* state, double lr, double beta1, double beta2, const 
 int launch_adam_step(float* p, float* g, float* m, float* v, size_t n, double lr, double beta1, double beta2, double eps, double wd,
                      int decoupled, int maximize, const float* state, const float* grad_scale, const float* found_inf, int write_grad,
                      hipStream_t s);
+int launch_pad_heads(const bf16_t* wqkv, const float* bqkv, const bf16_t* wo, bf16_t* wqkv_p, float* bqkv_p, bf16_t* wo_p, int D, int H,
+                     int hd, int hdp, hipStream_t s);
+int launch_unpad_head_grads(const float* gwqkv_p, const float* gbqkv_p, const float* gwo_p, float* gwqkv, float* gbqkv, float* gwo, int D,
+                            int H, int hd, int hdp, hipStream_t s);
 int launch_row_normalize(const float* f, bf16_t* fn, float* inv, int n, int p, float eps, hipStream_t s);
 int launch_row_normalize_bwd(const float* f, const float* inv, const float* dfn, float* df, int n, int p, hipStream_t s);
 int launch_nce_finalize(const float* partial, int ntiles, float inv_t, double npos, float* loss, float* stats, hipStream_t s);

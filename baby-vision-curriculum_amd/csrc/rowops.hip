@@ -656,6 +656,45 @@ __global__ void adam_step_kernel(float* __restrict__ p, float* __restrict__ g, f
     }
 }
 
+// ============================================================================ zero-padded attention heads (hd -> hdp)
+// The JEPA predictor inherits the encoder's head COUNT (vision_transformer.py:447,463: num_heads=encoder.num_heads), so ViT-L
+// gives 16 heads of 24 dims - not an MFMA-friendly width.  The heads are run at 32 dims with zero padding: padded copies of
+// the bf16 qkv / proj weights are made per use and the padded weight gradients are compacted back (all tiny: Dp = 384).
+//   qkv rows:  r' = (which * H + h) * hdp + j  <-  r = (which * H + h) * hd + j   (j < hd; other rows zero)
+//   proj cols: c' = h * hdp + j                <-  c = h * hd + j
+__global__ void pad_qkv_kernel(const bf16_t* __restrict__ w, const float* __restrict__ b, bf16_t* __restrict__ wp, float* __restrict__ bp,
+                               int H, int hd, int hdp, int D) {
+    const int rp = blockIdx.x;                       // padded row in [0, 3 H hdp)
+    const int j = rp % hdp, wh = rp / hdp;
+    const bool live = j < hd;
+    const int r = wh * hd + j;
+    for (int c = threadIdx.x; c < D; c += blockDim.x) wp[(size_t)rp * D + c] = live ? w[(size_t)r * D + c] : (bf16_t)0;
+    if (threadIdx.x == 0) bp[rp] = live ? b[r] : 0.f;
+}
+__global__ void pad_cols_kernel(const bf16_t* __restrict__ w, bf16_t* __restrict__ wp, int rows, int H, int hd, int hdp) {
+    const int r = blockIdx.x;
+    for (int cp = threadIdx.x; cp < H * hdp; cp += blockDim.x) {
+        const int j = cp % hdp, h = cp / hdp;
+        wp[(size_t)r * H * hdp + cp] = j < hd ? w[(size_t)r * H * hd + h * hd + j] : (bf16_t)0;
+    }
+}
+// gradients back to the reference's layout (plain stores: nothing else writes these ranges)
+__global__ void unpad_qkv_grad_kernel(const float* __restrict__ gwp, const float* __restrict__ gbp, float* __restrict__ gw,
+                                      float* __restrict__ gb, int H, int hd, int hdp, int D) {
+    const int r = blockIdx.x;                        // true row in [0, 3 H hd)
+    const int j = r % hd, wh = r / hd;
+    const int rp = wh * hdp + j;
+    for (int c = threadIdx.x; c < D; c += blockDim.x) gw[(size_t)r * D + c] = gwp[(size_t)rp * D + c];
+    if (threadIdx.x == 0) gb[r] = gbp[rp];
+}
+__global__ void unpad_cols_grad_kernel(const float* __restrict__ gwp, float* __restrict__ gw, int rows, int H, int hd, int hdp) {
+    const int r = blockIdx.x;
+    for (int c = threadIdx.x; c < H * hd; c += blockDim.x) {
+        const int j = c % hd, h = c / hd;
+        gw[(size_t)r * H * hd + c] = gwp[(size_t)r * H * hdp + h * hdp + j];
+    }
+}
+
 // ============================================================================ launchers
 static inline unsigned blocks_for(size_t items, int per = 256) { return (unsigned)((items + per - 1) / per); }
 
@@ -874,6 +913,22 @@ int launch_adam_step(float* p, float* g, float* m, float* v, size_t n, double lr
     hipLaunchKernelGGL(adam_step_kernel, dim3(blocks_for((n + 3) / 4)), dim3(256), 0, s, p, g, m, v, n, (float)(1.0 - beta1), (float)beta2,
                        (float)(1.0 - beta2), (float)eps, (float)wd, (float)(1.0 - lr * wd), decoupled, maximize, state, grad_scale,
                        found_inf, write_grad);
+    BVC_CHECK_HIP(hipGetLastError());
+    return BVC_OK;
+}
+
+int launch_pad_heads(const bf16_t* wqkv, const float* bqkv, const bf16_t* wo, bf16_t* wqkv_p, float* bqkv_p, bf16_t* wo_p, int D, int H,
+                     int hd, int hdp, hipStream_t s) {
+    hipLaunchKernelGGL(pad_qkv_kernel, dim3(3 * H * hdp), dim3(128), 0, s, wqkv, bqkv, wqkv_p, bqkv_p, H, hd, hdp, D);
+    hipLaunchKernelGGL(pad_cols_kernel, dim3(D), dim3(128), 0, s, wo, wo_p, D, H, hd, hdp);
+    BVC_CHECK_HIP(hipGetLastError());
+    return BVC_OK;
+}
+
+int launch_unpad_head_grads(const float* gwqkv_p, const float* gbqkv_p, const float* gwo_p, float* gwqkv, float* gbqkv, float* gwo, int D,
+                            int H, int hd, int hdp, hipStream_t s) {
+    hipLaunchKernelGGL(unpad_qkv_grad_kernel, dim3(3 * H * hd), dim3(128), 0, s, gwqkv_p, gbqkv_p, gwqkv, gbqkv, H, hd, hdp, D);
+    hipLaunchKernelGGL(unpad_cols_grad_kernel, dim3(D), dim3(128), 0, s, gwo_p, gwo, D, H, hd, hdp);
     BVC_CHECK_HIP(hipGetLastError());
     return BVC_OK;
 }

@@ -54,6 +54,12 @@ struct Stack {
     float eps;
     std::vector<LayerAct> act;
     float* x_out;     // f32 [M][D] output of the last layer
+    // attention width: heads of hd = D / H dims run at hdp dims (hdp == hd unless hd is not 32 / 64, e.g. 24 -> 32, zero padded);
+    // Da = H * hdp is the row width of qkv thirds and of ctx.  Scratch below exists only when hdp != hd.
+    int hd, hdp, Da;
+    bf16_t *wqkv_pad = nullptr, *wo_pad = nullptr;             // bf16 [3 Da][D], [D][Da]
+    float *bqkv_pad = nullptr;                                 // f32 [3 Da]
+    float *gwqkv_pad = nullptr, *gbqkv_pad = nullptr, *gwo_pad = nullptr;   // f32 gradients in the padded layout
 };
 
 // device allocations owned by a context

@@ -1,4 +1,5 @@
 // Shared pre-LN transformer stack: allocation, one-layer forward / backward schedules (host code).
+#include <math.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -63,13 +64,26 @@ LayerOff add_layer_params(ParamTable& t, const std::string& p, int64_t d, int64_
 
 int alloc_stack(Arena& a, Stack& s, int D, int I, int H, int nlayers, float eps, size_t M, size_t BHN) {
     s.D = D; s.I = I; s.H = H; s.nlayers = nlayers; s.eps = eps;
+    s.hd = D / H;
+    s.hdp = s.hd <= 32 ? 32 : 64;
+    BVC_REQUIRE(D % H == 0 && s.hd <= 64 && s.hd % 8 == 0, "stack: head_dim %d unsupported (multiples of 8 up to 64)", s.hd);
+    s.Da = H * s.hdp;
+    const size_t Da = s.Da;
+    if (s.hdp != s.hd) {
+        TRY(a.alloc(&s.wqkv_pad, 3 * Da * D));
+        TRY(a.alloc(&s.wo_pad, (size_t)D * Da));
+        TRY(a.alloc(&s.bqkv_pad, 3 * Da));
+        TRY(a.alloc(&s.gwqkv_pad, 3 * Da * D));
+        TRY(a.alloc(&s.gbqkv_pad, 3 * Da));
+        TRY(a.alloc(&s.gwo_pad, (size_t)D * Da));
+    }
     s.act.resize(nlayers);
     for (auto& l : s.act) {
         TRY(a.alloc(&l.x_in, M * D));
         TRY(a.alloc(&l.h, M * D));
         TRY(a.alloc(&l.ln1o, M * D));
-        TRY(a.alloc(&l.qkv, M * 3 * D));
-        TRY(a.alloc(&l.ctx, M * D));
+        TRY(a.alloc(&l.qkv, M * 3 * Da));
+        TRY(a.alloc(&l.ctx, M * Da));
         TRY(a.alloc(&l.lse, BHN));
         TRY(a.alloc(&l.ln2o, M * D));
         TRY(a.alloc(&l.pre, M * I));
@@ -155,14 +169,23 @@ int layer_forward(Work& w, Stack& s, int li, const LayerOff& o, const float* x_i
     const bf16_t* W = w.wbf;
     const float eps = s.eps;
     TRY(launch_ln_fwd(x_in, identity_rows(), P + o.ln1w, P + o.ln1b, a.ln1o, a.mean1, a.rstd1, M, D, eps, st));
+    const int Da = s.Da;
+    const bool pad = s.hdp != s.hd;
+    const bf16_t *Wqkv = W + o.wqkv, *Wo = W + o.wo;
+    const float* bqkv = P + o.bqkv;
+    const float sm_scale = pad ? 1.0f / sqrtf((float)s.hd) : 0.f;
+    if (pad) {
+        TRY(launch_pad_heads(W + o.wqkv, P + o.bqkv, W + o.wo, s.wqkv_pad, s.bqkv_pad, s.wo_pad, D, s.H, s.hd, s.hdp, st));
+        Wqkv = s.wqkv_pad; Wo = s.wo_pad; bqkv = s.bqkv_pad;
+    }
     {
-        GemmProblem p = gemm(a.ln1o, (size_t)M * D, D, W + o.wqkv, (size_t)3 * D * D, D, M, 3 * D, D, EPI_BF16, a.qkv, 3 * D);
-        p.bias = P + o.bqkv;
+        GemmProblem p = gemm(a.ln1o, (size_t)M * D, D, Wqkv, (size_t)3 * Da * D, D, M, 3 * Da, D, EPI_BF16, a.qkv, 3 * Da);
+        p.bias = bqkv;
         TRY(launch_gemm(&p, 1, GEMM_NT, -1, st));
     }
-    TRY(launch_attn_fwd(a.qkv, a.ctx, a.lse, B, N, s.H, s.D / s.H, st));
+    TRY(launch_attn_fwd(a.qkv, a.ctx, a.lse, B, N, s.H, s.hdp, st, sm_scale));
     {
-        GemmProblem p = gemm(a.ctx, (size_t)M * D, D, W + o.wo, (size_t)D * D, D, M, D, D, EPI_RESID, a.h, D);
+        GemmProblem p = gemm(a.ctx, (size_t)M * Da, Da, Wo, (size_t)D * Da, Da, M, D, Da, EPI_RESID, a.h, D);
         p.bias = P + o.bo; p.resid = x_in;
         TRY(launch_gemm(&p, 1, GEMM_NT, -1, st));
     }
@@ -216,13 +239,21 @@ int layer_backward(Work& c_, Stack& s, int li, const LayerOff& o, const float* x
     }
     TRY(launch_ln_bwd(c_.dln, a.h, identity_rows(), a.mean2, a.rstd2, P + o.ln2w, dres, 1, dhb, G + o.ln2w, G + o.ln2b, c_.ln_part, M, D, st));
     // attention
+    const int Da = s.Da;
+    const bool pad = s.hdp != s.hd;
+    const bf16_t *Wqkv = W + o.wqkv, *Wo = W + o.wo;
+    const float sm_scale = pad ? 1.0f / sqrtf((float)s.hd) : 0.f;
+    if (pad) {   // the padded weight copies are shared by all layers: rebuild this layer's
+        TRY(launch_pad_heads(W + o.wqkv, P + o.bqkv, W + o.wo, s.wqkv_pad, s.bqkv_pad, s.wo_pad, D, s.H, s.hd, s.hdp, st));
+        Wqkv = s.wqkv_pad; Wo = s.wo_pad;
+    }
     {
-        GemmProblem p = gemm(dhb, (size_t)M * D, D, W + o.wo, (size_t)D * D, D, M, D, D, EPI_BF16, c_.dctx, D);
+        GemmProblem p = gemm(dhb, (size_t)M * D, D, Wo, (size_t)D * Da, Da, M, Da, D, EPI_BF16, c_.dctx, Da);
         TRY(launch_gemm(&p, 1, GEMM_NN, -1, st));
     }
-    TRY(launch_attn_bwd(a.qkv, a.ctx, c_.dctx, a.lse, c_.delta, dqkv, B, N, s.H, s.D / s.H, st));
+    TRY(launch_attn_bwd(a.qkv, a.ctx, c_.dctx, a.lse, c_.delta, dqkv, B, N, s.H, s.hdp, st, sm_scale));
     {
-        GemmProblem p = gemm(dqkv, (size_t)M * 3 * D, 3 * D, W + o.wqkv, (size_t)3 * D * D, D, M, D, 3 * D, EPI_BF16, c_.dln, D);
+        GemmProblem p = gemm(dqkv, (size_t)M * 3 * Da, 3 * Da, Wqkv, (size_t)3 * Da * D, D, M, D, 3 * Da, EPI_BF16, c_.dln, D);
         TRY(launch_gemm(&p, 1, GEMM_NN, -1, st));
     }
     // the four weight gradients of the layer as one grouped launch:  dW = dY^T X,  db = column sums of dY
@@ -236,14 +267,21 @@ int layer_backward(Work& c_, Stack& s, int li, const LayerOff& o, const float* x
         GemmProblem g[4];
         g[0] = gemm(dyb, (size_t)M * D, D, a.act, (size_t)M * I, I, D, I, M, EPI_F32, G + o.w2, I);
         g[1] = gemm(dh, (size_t)M * I, I, a.ln2o, (size_t)M * D, D, I, D, M, EPI_F32, G + o.w1, D);
-        g[2] = gemm(dhb, (size_t)M * D, D, a.ctx, (size_t)M * D, D, D, D, M, EPI_F32, G + o.wo, D);
-        g[3] = gemm(dqkv, (size_t)M * 3 * D, 3 * D, a.ln1o, (size_t)M * D, D, 3 * D, D, M, EPI_F32, G + o.wqkv, D);
+        g[2] = gemm(dhb, (size_t)M * D, D, a.ctx, (size_t)M * Da, Da, D, Da, M, EPI_F32, pad ? s.gwo_pad : G + o.wo, Da);
+        g[3] = gemm(dqkv, (size_t)M * 3 * Da, 3 * Da, a.ln1o, (size_t)M * D, D, 3 * Da, D, M, EPI_F32, pad ? s.gwqkv_pad : G + o.wqkv, D);
         g[0].rowsum = G + o.b2;     // bias gradients ride along as one extra MFMA column each
         g[1].rowsum = G + o.b1;
         g[2].rowsum = G + o.bo;
-        g[3].rowsum = G + o.bqkv;
+        g[3].rowsum = pad ? s.gbqkv_pad : G + o.bqkv;
         const int tile = plan_dw(g, 4);
+        if (pad) {   // split-K accumulates with atomics: the padded scratch is zeroed like the gradient buffer is
+            BVC_CHECK_HIP(hipMemsetAsync(s.gwo_pad, 0, (size_t)D * Da * 4, ws));
+            BVC_CHECK_HIP(hipMemsetAsync(s.gwqkv_pad, 0, (size_t)3 * Da * D * 4, ws));
+            BVC_CHECK_HIP(hipMemsetAsync(s.gbqkv_pad, 0, (size_t)3 * Da * 4, ws));
+        }
         TRY(launch_gemm(g, 4, GEMM_TN, tile, ws));
+        if (pad)
+            TRY(launch_unpad_head_grads(s.gwqkv_pad, s.gbqkv_pad, s.gwo_pad, G + o.wqkv, G + o.bqkv, G + o.wo, D, s.H, s.hd, s.hdp, ws));
     }
     TRY(launch_ln_bwd(c_.dln, x_in, identity_rows(), a.mean1, a.rstd1, P + o.ln1w, dres, 1, dyb_next, G + o.ln1w, G + o.ln1b, c_.ln_part, M, D, st));
     if (c_.overlap) {

@@ -51,6 +51,9 @@ class JepaConfig:
 
 VIT_B = JepaConfig()                                                    # slurmscripts/predictive: ViT-B, 2 frames, tubelet 1
 TINY = JepaConfig(image_size=64, patch_size=16, embed_dim=128, depth=2, num_heads=2, pred_dim=64, pred_depth=1)   # head dims 64 / 32
+# predictor heads of 24 dims, as vit_large gives (16 heads on 384 dims, vision_transformer.py:447,572-576): 8 heads on 192 dims
+TINY_HD24 = JepaConfig(image_size=64, patch_size=16, embed_dim=512, depth=1, num_heads=8, pred_dim=192, pred_depth=2)
+VIT_L = JepaConfig(embed_dim=1024, depth=24, num_heads=16)
 
 
 def positional_encoding_3d(sequence_shape, channels_out):

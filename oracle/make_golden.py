@@ -185,7 +185,8 @@ def jepa_fixture():
     import mask as rmask
     from functools import partial
     cases = []
-    for name, cfg, B, n_ctx, n_pred, seed in [("tiny", jo.TINY, 3, 6, 4, 0), ("tiny_b", jo.TINY, 2, 9, 5, 1), ("vit_b", jo.VIT_B, 2, 83, 25, 0)]:
+    for name, cfg, B, n_ctx, n_pred, seed in [("tiny", jo.TINY, 3, 6, 4, 0), ("tiny_b", jo.TINY, 2, 9, 5, 1), ("vit_b", jo.VIT_B, 2, 83, 25, 0),
+                                                ("tiny_hd24", jo.TINY_HD24, 2, 7, 5, 2)]:
         enc_p = jo.make_params(jo.encoder_shapes(cfg), cfg, seed)
         pred_p = jo.make_params(jo.predictor_shapes(cfg), cfg, seed + 50)
         tgt_p = jo.make_params(jo.encoder_shapes(cfg), cfg, seed + 100)

@@ -35,7 +35,7 @@ def _modules(cfg, enc_p, pred_p, tgt_p):
     return enc.to(dev), pred.to(dev), tgt.to(dev)
 
 
-@pytest.mark.parametrize("idx", [0, 1, 2])
+@pytest.mark.parametrize("idx", [0, 1, 2, 3])     # 3 = predictor heads of 24 dims (ViT-L's shape), run zero-padded to 32
 def test_train_step_matches_oracle_and_fixture(golden_dir, idx):
     c = json.load(open(os.path.join(golden_dir, "jepa.json")))["cases"][idx]
     cfg = jo.JepaConfig(**c["config"])

@@ -16,7 +16,7 @@ def fx(golden_dir):
     return json.load(open(os.path.join(golden_dir, "jepa.json")))
 
 
-@pytest.mark.parametrize("idx", [0, 1, 2])
+@pytest.mark.parametrize("idx", [0, 1, 2, 3])
 def test_oracle_matches_reference_fixture(fx, idx):
     c = fx["cases"][idx]
     cfg = jo.JepaConfig(**c["config"])

@@ -86,10 +86,15 @@ def main():
                 best = r
             if tile < 0:
                 auto = r
+        os.environ["BVC_GEMM_LEGACY_WALK"] = "1"      # same-run A/B of the L2-aware tile walk (gemm.hip: pick_panel)
+        legacy = gemm_case(name, lay, M, N, K, -1, split, epi, -1)
+        os.environ.pop("BVC_GEMM_LEGACY_WALK", None)
+        legacy["walk"] = "legacy"
+        out.append(legacy)
+        line = f"{name:12s} auto {auto['ms']*1e3:7.1f}us {auto['tflops']:6.1f}TF | legacy walk {legacy['ms']*1e3:7.1f}us {legacy['tflops']:6.1f}TF"
         if best:
-            print(f"{name:12s} auto {auto['ms']*1e3:7.1f}us {auto['tflops']:6.1f}TF | best tile{best['tile']} st{best['stages']} {best['ms']*1e3:7.1f}us {best['tflops']:6.1f}TF", flush=True)
-        else:
-            print(auto, flush=True)
+            line += f" | best tile{best['tile']} st{best['stages']} {best['ms']*1e3:7.1f}us {best['tflops']:6.1f}TF"
+        print(line, flush=True)
     # the grouped weight-gradient launch of one layer (4 problems, fused bias gradients)
     for tag, M, D, I in (("enc", Me, 768, 3072), ("dec", Md, 384, 1536)):
         dy, act = G.bf16_randn(M, D, seed=7), G.bf16_randn(M, I, seed=8)
@@ -98,7 +103,19 @@ def main():
         outs = [torch.zeros(D, I, device=dev), torch.zeros(I, D, device=dev), torch.zeros(D, D, device=dev), torch.zeros(3 * D, D, device=dev)]
         bs = [torch.zeros(D, device=dev), torch.zeros(I, device=dev), torch.zeros(D, device=dev), torch.zeros(3 * D, device=dev)]
         flops = 2.0 * M * (D * I * 2 + D * D * 4)
-        for split in ((1, 2) if tag == "enc" else (2, 4, 6)):
+        for walk in ("panel", "legacy"):
+            if walk == "legacy":
+                os.environ["BVC_GEMM_LEGACY_WALK"] = "1"
+            sp, tl = (1, 0) if tag == "enc" and Bc <= 16 else (4, 0)
+            descs = [G.gemm_desc(dy, act, D, I, M, G.EPI["F32"], outs[0], rowsum=bs[0], split_k=sp),
+                     G.gemm_desc(dh, ln2, I, D, M, G.EPI["F32"], outs[1], rowsum=bs[1], split_k=sp),
+                     G.gemm_desc(dy, ln2, D, D, M, G.EPI["F32"], outs[2], rowsum=bs[2], split_k=sp),
+                     G.gemm_desc(dqkv, ln2, 3 * D, D, M, G.EPI["F32"], outs[3], rowsum=bs[3], split_k=sp)]
+            ms = timeit(lambda: G.run_gemm(descs, G.TN, tl, 2))
+            os.environ.pop("BVC_GEMM_LEGACY_WALK", None)
+            r = {"name": f"{tag} dW group", "walk": walk, "tile": tl, "split": sp, "ms": round(ms, 4), "tflops": round(flops / ms / 1e9, 1)}
+            out.append(r); print(r, flush=True)
+        for split in (() if not sweep else ((1, 2) if tag == "enc" else (2, 4, 6))):
             for tile in (0, 1, 2):
                 descs = [G.gemm_desc(dy, act, D, I, M, G.EPI["F32"], outs[0], rowsum=bs[0], split_k=split),
                          G.gemm_desc(dh, ln2, I, D, M, G.EPI["F32"], outs[1], rowsum=bs[1], split_k=split),

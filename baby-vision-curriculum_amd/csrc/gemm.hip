@@ -506,7 +506,10 @@ int gemm_pick_tile(const GemmProblem* probs, int nprob, int tile_cfg) {
 // ~2 MiB of the L2 and otherwise once per resident wave of 64 workgroups.  Candidates: no panels, or the widest panel that fits.
 static int pick_panel(const GemmProblem& p, int cfg, GemmLayout layout) {
     if (getenv("BVC_GEMM_LEGACY_WALK") != nullptr) return 0;     // read per launch: same-process A/B (tools/microbench.py)
-    (void)layout;
+    // Same-box A/B at B=64 (profiles/r01_e_walk_ab_b64.txt): the panel walk is worth +5 % on the encoder fc1 shape and is
+    // neutral elsewhere for NT / NN; the split-K weight-gradient launches are 2-10 % FASTER with the legacy walk (splits
+    // fastest, short side first) although it fetches more - the Infinity Cache absorbs the re-reads - so TN keeps it.
+    if (layout == GEMM_TN) return 0;
     int bm, bn;
     tile_dims(cfg, bm, bn);
     const int tiles_m = (p.M + bm - 1) / bm, tiles_n = (p.N + bn - 1) / bn;

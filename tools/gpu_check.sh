@@ -40,6 +40,8 @@ for step in "$@"; do
     dwsweep) run dwsweep 400 python tools/dw_sweep.py ;;
     probe) run probe 300 python tools/gemm_probe.py ;;
     jepa) run jepa 400 python tools/bench_jepa.py ;;
+    jepal) run jepal 400 python tools/bench_jepa.py --model vit_large ;;
+    simclrvit) run simclrvit 400 python tools/bench_simclr.py --vit ;;
     encode) run encode 300 python tools/bench_encode.py ;;
     simclr) run simclr 400 python tools/bench_simclr.py ;;
     prof)  rm -rf $OUT/prof; cd /tmp

@@ -29,6 +29,7 @@ struct GemmGroup {
     int nprob;
     int tile_start[kMaxGroup + 1];
     int panel[kMaxGroup];          // column tiles per panel of the tile walk (0 = the legacy walk, A/B only); see pick_panel
+    int dbg;                       // BVC_GEMM_DEBUG experiments (tools/gemm_dbg.py): 1 = drop the bf16 stores, 2 = stagger odd slots
     GemmProblem prob[kMaxGroup];
 };
 
@@ -111,6 +112,7 @@ __global__ __launch_bounds__(256, LB) void gemm_kernel(const GemmGroup g) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
+    if ((g.dbg & 2) && ((blockIdx.x >> 3) & 1)) __builtin_amdgcn_s_sleep(100);
 
     // XCD-aware remap (bijective for any grid size): XCD x owns a contiguous run of logical ids
     const int nb = gridDim.x, bid = blockIdx.x;
@@ -314,37 +316,64 @@ __global__ __launch_bounds__(256, LB) void gemm_kernel(const GemmGroup g) {
     } else if (nt > 0 || !atomic) {
         constexpr int CPR = WN / 8;                     // 8-column chunks per row
         constexpr int NCH = WM * WN / 8 / 64;           // chunks per lane
-#pragma unroll 2
+        // Chunk `it` of a lane is row it * (64 / CPR) + lane / CPR, columns 8 (lane % CPR) .. +7: the columns never change.
+        const int cc = lane % CPR, rsub = lane / CPR;
+        const int n = n0 + wn * WN + cc * 8;
+        const bool ncol_ok = n < p.N;
+        // On gfx950 loads and stores retire through ONE in-order counter (vmcnt): a load issued after a store cannot be
+        // waited for without waiting for that store's write acknowledgement too.  The epilogue used to alternate
+        // "load side input, compute, store" per chunk and so paid one store round trip per chunk - measured as ~5 us of fixed
+        // cost per tile (tools/gemm_dbg.py: decoder fc1 340 us, 201 us with the stores dropped).  All side inputs of the tile
+        // (bias, residual, GELU' argument, labels, positional rows) are therefore fetched FIRST, into registers the parked
+        // accumulators no longer need, and the stores follow back to back.
+        f32x4 bias0 = {0.f, 0.f, 0.f, 0.f}, bias1 = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias && (!atomic || split == 0) && ncol_ok) {
+            bias0 = *reinterpret_cast<const f32x4*>(p.bias + n);
+            bias1 = *reinterpret_cast<const f32x4*>(p.bias + n + 4);
+        }
+        f32x4 side0[NCH], side1[NCH];     // f32 addend (residual / positional row / labels) or the 4 dwords of the bf16 aux row
+        const bool side_f32 = (epi == EPI_RESID && !atomic) || epi == EPI_POS || epi == EPI_E2D || epi == EPI_LOSS;
+        const bool side_aux = epi == EPI_DGELU || epi == EPI_DRELU;
+        if (side_f32 || side_aux) {
+#pragma unroll
+            for (int it = 0; it < NCH; ++it) {
+                const int m = m0 + wm * WM + it * (64 / CPR) + rsub;
+                side0[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+                side1[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (m >= p.M || !ncol_ok) continue;
+                if (side_aux) {
+                    side0[it] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const bf16_t*>(p.aux) + (size_t)m * p.ldaux + n);
+                } else {
+                    const float* src = epi == EPI_RESID ? p.resid + (size_t)m * p.ldc + n
+                                     : epi == EPI_LOSS  ? p.labels + (size_t)m * p.ldc + n
+                                                        : p.pos + (size_t)p.rowtok[m] * p.N + n;
+                    side0[it] = *reinterpret_cast<const f32x4*>(src);
+                    side1[it] = *reinterpret_cast<const f32x4*>(src + 4);
+                }
+            }
+        }
+#pragma unroll
         for (int it = 0; it < NCH; ++it) {
-            const int id = it * 64 + lane;
-            const int row = id / CPR, cc = id % CPR;
+            const int row = it * (64 / CPR) + rsub;
             const int m = m0 + wm * WM + row;
-            const int n = n0 + wn * WN + cc * 8;
             const f32x4 lo = *reinterpret_cast<const AS3 f32x4*>(wl + row * (WN * 4) + (((2 * cc) ^ (row & (UNITS - 1))) << 4));
             const f32x4 hi = *reinterpret_cast<const AS3 f32x4*>(wl + row * (WN * 4) + (((2 * cc + 1) ^ (row & (UNITS - 1))) << 4));
-            if (m >= p.M || n >= p.N) continue;
-            float v[8] = {lo[0] * alpha, lo[1] * alpha, lo[2] * alpha, lo[3] * alpha,
-                          hi[0] * alpha, hi[1] * alpha, hi[2] * alpha, hi[3] * alpha};
-            if (p.bias && (!atomic || split == 0)) {
-                const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + n);
-                const f32x4 b1 = *reinterpret_cast<const f32x4*>(p.bias + n + 4);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
-            }
+            if (m >= p.M || !ncol_ok) continue;
+            float v[8] = {lo[0] * alpha + bias0[0], lo[1] * alpha + bias0[1], lo[2] * alpha + bias0[2], lo[3] * alpha + bias0[3],
+                          hi[0] * alpha + bias1[0], hi[1] * alpha + bias1[1], hi[2] * alpha + bias1[2], hi[3] * alpha + bias1[3]};
             const size_t idx = (size_t)m * p.ldc + n;
             auto store_f32 = [&](float* dst) {
                 *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
                 *reinterpret_cast<f32x4*>(dst + 4) = f32x4{v[4], v[5], v[6], v[7]};
             };
             auto store_bf16 = [&](void* base, size_t at, const float* w) {
+                if (g.dbg & 1) return;
                 *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(base) + at) =
                     uint4{pack2bf(w[0], w[1]), pack2bf(w[2], w[3]), pack2bf(w[4], w[5]), pack2bf(w[6], w[7])};
             };
-            auto add8 = [&](const float* src) {
-                const f32x4 a0 = *reinterpret_cast<const f32x4*>(src);
-                const f32x4 a1 = *reinterpret_cast<const f32x4*>(src + 4);
+            auto add_side = [&]() {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { v[e] += a0[e]; v[4 + e] += a1[e]; }
+                for (int e = 0; e < 4; ++e) { v[e] += side0[it][e]; v[4 + e] += side1[it][e]; }
             };
             switch (epi) {
                 case EPI_F32: {
@@ -370,32 +399,30 @@ __global__ __launch_bounds__(256, LB) void gemm_kernel(const GemmGroup g) {
 #pragma unroll
                         for (int e = 0; e < 8; ++e) atomicAdd(c + e, v[e]);
                     } else {
-                        add8(p.resid + idx);
+                        add_side();
                         store_f32(c);
                     }
                 } break;
                 case EPI_POS: {
-                    add8(p.pos + (size_t)p.rowtok[m] * p.N + n);
+                    add_side();
                     store_f32(reinterpret_cast<float*>(p.C) + idx);
                 } break;
                 case EPI_E2D: {
-                    add8(p.pos + (size_t)p.rowtok[m] * p.N + n);
+                    add_side();
                     const size_t orow = (size_t)(m / p.rin) * p.rout + (m % p.rin);
                     store_f32(reinterpret_cast<float*>(p.C) + orow * p.ldc + n);
                 } break;
                 case EPI_LOSS: {
                     if (p.C2) store_f32(reinterpret_cast<float*>(p.C2) + idx);
-                    const f32x4 l0 = *reinterpret_cast<const f32x4*>(p.labels + idx);
-                    const f32x4 l1 = *reinterpret_cast<const f32x4*>(p.labels + idx + 4);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { v[e] -= l0[e]; v[4 + e] -= l1[e]; }
+                    for (int e = 0; e < 4; ++e) { v[e] -= side0[it][e]; v[4 + e] -= side1[it][e]; }
 #pragma unroll
                     for (int e = 0; e < 8; ++e) sumsq += v[e] * v[e];
                     store_bf16(p.C, idx, v);
                 } break;
                 case EPI_DGELU: {
-                    const uint4 a = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(p.aux) + (size_t)m * p.ldaux + n);
-                    const uint32_t w[4] = {a.x, a.y, a.z, a.w};
+                    const uint32_t w[4] = {__float_as_uint(side0[it][0]), __float_as_uint(side0[it][1]), __float_as_uint(side0[it][2]),
+                                           __float_as_uint(side0[it][3])};
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         v[2 * e] *= dgelu_f(__uint_as_float(w[e] << 16));
@@ -413,8 +440,8 @@ __global__ __launch_bounds__(256, LB) void gemm_kernel(const GemmGroup g) {
                     store_bf16(p.C, idx, v);
                 } break;
                 case EPI_DRELU: {   // aux = the forward ReLU output: gradient passes where it was positive
-                    const uint4 a = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(p.aux) + (size_t)m * p.ldaux + n);
-                    const uint32_t w[4] = {a.x, a.y, a.z, a.w};
+                    const uint32_t w[4] = {__float_as_uint(side0[it][0]), __float_as_uint(side0[it][1]), __float_as_uint(side0[it][2]),
+                                           __float_as_uint(side0[it][3])};
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         if (!((w[e] & 0x7fffu) && !(w[e] & 0x8000u))) v[2 * e] = 0.f;
@@ -577,6 +604,10 @@ int launch_gemm(const GemmProblem* probs, int nprob, GemmLayout layout, int tile
     const int cfg = gemm_pick_tile(probs, nprob, tile_cfg);
     GemmGroup g;
     g.nprob = nprob;
+    {
+        const char* e = getenv("BVC_GEMM_DEBUG");
+        g.dbg = e ? atoi(e) : 0;
+    }
     int total = 0;
     for (int i = 0; i < nprob; ++i) {
         const GemmProblem& p = probs[i];

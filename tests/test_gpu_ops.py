@@ -268,7 +268,7 @@ def test_attention_sharp_softmax():
 
 
 # --------------------------------------------------------------------------- LayerNorm, column sums
-@pytest.mark.parametrize("M,D", [(160, 768), (1000, 384), (37, 128), (8, 64), (50, 1024), (20000, 384)])
+@pytest.mark.parametrize("M,D", [(160, 768), (1000, 384), (37, 128), (8, 64), (50, 1024), (20000, 384), (70001, 384)])
 def test_layernorm_forward_backward(M, D):
     g = torch.Generator().manual_seed(40)
     x = (torch.randn(M, D, generator=g) * 2 + 0.5).to(dev)

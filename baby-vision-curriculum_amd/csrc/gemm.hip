@@ -599,13 +599,13 @@ static int launch_stages(const GemmGroup& g, GemmLayout layout, int stages, int 
 // slower (they cost the second resident workgroup per CU), so `stages` is accepted for API stability and ignored.
 int gemm_pick_stages(int, GemmLayout, int, int stages) { return (stages == 3 || stages == 4) ? stages : 2; }
 
-int launch_gemm_big_nt(const GemmProblem& p, hipStream_t stream);   // gemm_big.hip (experiment)
+int launch_gemm_big_nt(const GemmProblem& p, int cfg, hipStream_t stream);   // gemm_big.hip (experiments: tile configs 3-5)
 
 int launch_gemm(const GemmProblem* probs, int nprob, GemmLayout layout, int tile_cfg, hipStream_t stream, int stages) {
     BVC_REQUIRE(nprob >= 1 && nprob <= kMaxGroup, "launch_gemm: nprob %d out of range", nprob);
-    if (tile_cfg == 3) {
-        BVC_REQUIRE(nprob == 1 && layout == GEMM_NT, "launch_gemm: tile config 3 (256x128) is NT, one problem");
-        return launch_gemm_big_nt(probs[0], stream);
+    if (tile_cfg >= 3) {
+        BVC_REQUIRE(tile_cfg <= 5 && nprob == 1 && layout == GEMM_NT, "launch_gemm: tile configs 3-5 (32-deep K steps) are NT, one problem");
+        return launch_gemm_big_nt(probs[0], tile_cfg, stream);
     }
     const int cfg = gemm_pick_tile(probs, nprob, tile_cfg);
     GemmGroup g;

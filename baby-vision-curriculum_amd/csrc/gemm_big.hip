@@ -39,9 +39,12 @@ __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :
 
 }  // namespace
 
-__global__ __launch_bounds__(256, 2) void gemm_nt_256x128_kernel(const GemmProblem p) {
+// BM = 256: 128x64 wave tiles, 48 KiB LDS, 2 workgroups / CU.  BM = 128: 64x64 wave tiles, 32 KiB LDS, LB workgroups / CU
+// (tile config 4: LB = 4, the occupancy experiment - do more resident workgroups hide the store drain of short-K products?)
+template <int BM, int LB>
+__global__ __launch_bounds__(256, LB) void gemm_nt_bk32_kernel(const GemmProblem p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int BM = 256, BN = 128, BK = 32, WM = 128, WN = 64, TM = 8, TN = 4;
+    constexpr int BN = 128, BK = 32, WM = BM / 2, WN = 64, TM = WM / 16, TN = 4;
     constexpr int A_BYTES = BM * BK * 2, STAGE = (BM + BN) * BK * 2;
     constexpr int DMA_PER_STAGE = (BM + BN) / 16 / 4;   // 6 LDS-DMA instructions per wave per stage
     const int tid = threadIdx.x, lane = tid & 63;
@@ -110,11 +113,15 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_256x128_kernel(const GemmProbl
     }
 }
 
-int launch_gemm_big_nt(const GemmProblem& p, hipStream_t stream) {
-    BVC_REQUIRE(p.epi == EPI_BF16 && p.split_k == 1, "gemm 256x128: EPI_BF16 without split-K only (experiment)");
-    BVC_REQUIRE(p.K % 32 == 0 && p.N % 8 == 0 && p.lda % 8 == 0 && p.ldb % 8 == 0 && p.ldc % 8 == 0, "gemm 256x128: K %% 32, N %% 8");
-    const int tiles = ((p.M + 255) / 256) * ((p.N + 127) / 128);
-    hipLaunchKernelGGL(gemm_nt_256x128_kernel, dim3(tiles), dim3(256), 2 * (256 + 128) * 32 * 2, stream, p);
+int launch_gemm_big_nt(const GemmProblem& p, int cfg, hipStream_t stream) {
+    BVC_REQUIRE(p.epi == EPI_BF16 && p.split_k == 1, "gemm bk32: EPI_BF16 without split-K only (experiment)");
+    BVC_REQUIRE(p.K % 32 == 0 && p.N % 8 == 0 && p.lda % 8 == 0 && p.ldb % 8 == 0 && p.ldc % 8 == 0, "gemm bk32: K %% 32, N %% 8");
+    const int bm = cfg == 3 ? 256 : 128;
+    const int tiles = ((p.M + bm - 1) / bm) * ((p.N + 127) / 128);
+    const size_t lds = 2 * (size_t)(bm + 128) * 32 * 2;
+    if (cfg == 3) hipLaunchKernelGGL((gemm_nt_bk32_kernel<256, 2>), dim3(tiles), dim3(256), lds, stream, p);
+    else if (cfg == 4) hipLaunchKernelGGL((gemm_nt_bk32_kernel<128, 4>), dim3(tiles), dim3(256), lds, stream, p);
+    else hipLaunchKernelGGL((gemm_nt_bk32_kernel<128, 3>), dim3(tiles), dim3(256), lds, stream, p);
     BVC_CHECK_HIP(hipGetLastError());
     return BVC_OK;
 }

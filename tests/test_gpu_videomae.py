@@ -118,11 +118,13 @@ def test_base_step_matches_oracle_and_fixture(golden_dir, case):
     _check_step(case, vo.BASE, fx["batch"], fx["seed"], fx["mask_ratio"], wseed=fx["weight_seed"], fixture=fx)
 
 
-def test_full_batch_properties():
-    """BASELINE batch (16 clips): size-independent properties instead of a 16-clip CPU run."""
+@pytest.mark.parametrize("nb", [16, 64])
+def test_full_batch_properties(nb):
+    """BASELINE batches (16 clips = the reference's slurm default, 64 = bench.py's default): size-independent properties
+    instead of a full-batch CPU run."""
     cfg = vo.BASE
     params = vo.make_params(cfg, seed=0)
-    pixels, mask = vo.synthetic_batch(cfg, 16, seed=11, mask_ratio=0.9)
+    pixels, mask = vo.synthetic_batch(cfg, nb, seed=11, mask_ratio=0.9)
     model = _model(cfg, params)
     px, mk = pixels.to(dev), mask.to(dev)
     out = model(px, bool_masked_pos=mk)
@@ -131,10 +133,10 @@ def test_full_batch_properties():
     l16 = float(out.loss)
     g16 = model.flat_grads().clone()
     assert np.isfinite(l16) and torch.isfinite(g16).all()
-    # the loss is a mean over clips: the 16-clip loss equals the mean of the two 8-clip losses, and the
+    # the loss is a mean over clips: the full-batch loss equals the mean of the two half-batch losses, and the
     # gradient is the mean of the two half-batch gradients (linearity of the batch mean)
     halves, grads = [], []
-    for sl in (slice(0, 8), slice(8, 16)):
+    for sl in (slice(0, nb // 2), slice(nb // 2, nb)):
         for p in model.parameters():
             p.grad = None
         o = model(px[sl], bool_masked_pos=mk[sl])
@@ -144,7 +146,7 @@ def test_full_batch_properties():
         grads.append(model.flat_grads().clone())
     assert abs(l16 - 0.5 * (halves[0] + halves[1])) / l16 < 1e-5
     e = G.rel_err(g16, 0.5 * (grads[0] + grads[1]))
-    _log(f"[b16] batch-mean linearity of the gradient: rel {e:.2e}")
+    _log(f"[b{nb}] batch-mean linearity of the gradient: rel {e:.2e}")
     assert e < 2e-2
     # the forward is deterministic (fixed-order loss reduction)
     for p in model.parameters():
@@ -320,3 +322,14 @@ def test_uint8_frames_equal_loader_normalised_f32_bitwise():
     a = enc(pixel_values=((u8.float() / 255.0 - mean) / std).to(dev)).logits
     b = enc(pixel_values=u8.to(dev)).logits
     assert torch.equal(a, b)
+
+
+
+@pytest.mark.parametrize("frames,tubelet,image,patch,ratio,B", [(2, 1, 64, 16, 0.75, 3), (8, 2, 96, 16, 0.9, 2), (4, 4, 64, 16, 0.5, 5),
+                                                              (4, 2, 128, 32, 0.75, 1)])
+def test_config_matrix_small(frames, tubelet, image, patch, ratio, B):
+    """Geometry edge cases of the reference's CLI surface (--num_frames / --tubelet_size, pretrain_videomae.py:383-493; other
+    image / patch sizes through the config): ragged tile edges, one-clip batches, tube depth = all frames."""
+    import dataclasses
+    cfg = dataclasses.replace(vo.TINY, num_frames=frames, tubelet_size=tubelet, image_size=image, patch_size=patch)
+    _check_step(f"cfg_f{frames}_t{tubelet}_i{image}_p{patch}", cfg, B, seed=7, ratio=ratio)

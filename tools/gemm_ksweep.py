@@ -31,19 +31,19 @@ def run(M, N, K, layout, epi, tile):
     if epi == "DGELU":
         kw = dict(aux=G.bf16_randn(M, N, seed=3))
     d = G.gemm_desc(A, B, M, N, K, G.EPI[epi], C, **kw)
-    if tile == 3 and K == 384:      # correctness of the experimental kernel against the 128x128 one (same operands)
+    if tile >= 3 and K == 384:      # correctness of the experimental kernel against the 128x128 one (same operands)
         C0 = torch.zeros_like(C)
         G.run_gemm([G.gemm_desc(A, B, M, N, K, G.EPI[epi], C0, **kw)], layout, 0, -1)
-        G.run_gemm([d], layout, 3, -1)
+        G.run_gemm([d], layout, tile, -1)
         torch.cuda.synchronize()
-        emit(f"   tile3 vs tile0 at K={K}: max abs diff {float((C.float() - C0.float()).abs().max()):.3e}, ref max {float(C0.float().abs().max()):.2f}")
+        emit(f"   tile{tile} vs tile0 at K={K}: max abs diff {float((C.float() - C0.float()).abs().max()):.3e}, ref max {float(C0.float().abs().max()):.2f}")
     return timeit(lambda: G.run_gemm([d], layout, tile, -1), iters=10, warm=2)
 
 
 Bc = int(os.environ.get("BVC_BATCH", "64"))
 M = Bc * 1568
 for N, layout, epi in ((1152, G.NT, "BF16"), (1536, G.NT, "GELU"), (1536, G.NN, "DGELU"), (384, G.NT, "BF16")):
-    for tile in ((0, 1, 2, 3) if (layout == G.NT and epi == "BF16") else (0, 1, 2)):
+    for tile in ((0, 1, 2, 3, 4, 5) if (layout == G.NT and epi == "BF16") else (0,)):
         row = []
         for K in (64, 128, 256, 384, 768, 1536):
             ms = run(M, N, K, layout, epi, tile)
@@ -51,7 +51,7 @@ for N, layout, epi in ((1152, G.NT, "BF16"), (1536, G.NT, "GELU"), (1536, G.NN, 
         (k0, t0), (k1, t1) = row[0], row[-1]
         slope = (t1 - t0) / (k1 - k0)
         icpt = t0 - slope * k0
-        tiles = -(-M // (256 if tile == 3 else 128 if tile < 2 else 64)) * -(-N // (128 if tile in (0, 3) else 64))
+        tiles = -(-M // (256 if tile == 3 else 64 if tile == 2 else 128)) * -(-N // (64 if tile in (1, 2) else 128))
         emit(f"M={M} N={N} {['NT','NN','TN'][layout]} {epi:5s} tile{tile}: " + " ".join(f"K{k}={ms*1e3:.0f}us" for k, ms in row) +
              f" | intercept {icpt*1e3:.0f}us slope {2.0*M*N/slope/1e9:.0f}TF marginal | {tiles} tiles")
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)

@@ -19,84 +19,11 @@
 //     weight-gradient products of one transformer layer.
 #include <stdlib.h>
 
-#include "gemm.h"
+#include "gemm_tile.h"
 
 namespace bvc {
 
-#define AS3 __attribute__((address_space(3)))
 
-struct GemmGroup {
-    int nprob;
-    int tile_start[kMaxGroup + 1];
-    int panel[kMaxGroup];          // column tiles per panel of the tile walk (0 = the legacy walk, A/B only); see pick_panel
-    int dbg;                       // BVC_GEMM_DEBUG experiments (tools/gemm_dbg.py): 1 = drop the bf16 stores, 2 = stagger odd slots
-    GemmProblem prob[kMaxGroup];
-};
-
-// ------------------------------------------------------------------ swizzles (16-byte chunk index)
-// k-contiguous image [rows][64] bf16, 128-B rows, read by ds_read_b128 (16 lanes = 16 rows, same chunk)
-__device__ __forceinline__ int swz_rows(int r) { return (r >> 1) & 7; }
-// transposed images [64 k][BR] bf16, read by ds_read_b64_tr_b16 (a 32-lane half = 8 k-rows x 32 B)
-template <int BR>
-__device__ __forceinline__ int swz_tr(int k) {
-    if constexpr (BR == 128) return ((k & 3) | (((k >> 3) & 1) << 2)) << 1;   // 256-B rows
-    else return (((k >> 1) & 1) | (((k >> 3) & 1) << 1)) << 1;                  // 128-B rows
-}
-
-// ------------------------------------------------------------------ HBM -> LDS staging of one operand tile
-// Non-transposed: rows r0..r0+BR-1 (output dim), k0..k0+63 of a [R][ld] array -> image [BR][64].
-// Transposed:     k rows k0..k0+63, columns r0..r0+BR-1 of a [Kc][ld] array    -> image [64][BR].
-template <int BR, bool T>
-__device__ __forceinline__ void stage_tile(__amdgpu_buffer_rsrc_t rs, int r0, int k0, int ld, char* lds,
-                                           int wave, int lane) {
-    constexpr int PIECES = BR * 64 * 2 / 1024;
-#pragma unroll
-    for (int jj = 0; jj < PIECES / 4; ++jj) {
-        const int j = wave + 4 * jj;   // wave-uniform piece index; piece j = LDS bytes [1024 j, 1024 j + 1024)
-        uint32_t off;
-        if constexpr (!T) {
-            const int r = 8 * j + (lane >> 3);
-            const int c = (lane & 7) ^ swz_rows(r);
-            off = (uint32_t)(((r0 + r) * ld + k0 + c * 8) * 2);
-        } else if constexpr (BR == 128) {
-            const int kr = 4 * j + (lane >> 4);
-            const int c = (lane & 15) ^ swz_tr<128>(kr);
-            off = (uint32_t)(((k0 + kr) * ld + r0 + c * 8) * 2);
-        } else {
-            const int kr = 8 * j + (lane >> 3);
-            const int c = (lane & 7) ^ swz_tr<64>(kr);
-            off = (uint32_t)(((k0 + kr) * ld + r0 + c * 8) * 2);
-        }
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(lds + j * 1024), 16, off, 0, 0, 0);
-    }
-}
-
-// ------------------------------------------------------------------ LDS -> MFMA fragment
-// Returns, for lane l, the 8 bf16  X[out = rbase + (l & 15)][k = 32 ks + 8 (l >> 4) + 0..7].
-template <int BR, bool T>
-__device__ __forceinline__ bf16x8 read_frag(const char* lds, int rbase, int ks, int lane) {
-    if constexpr (!T) {
-        const int r = rbase + (lane & 15);
-        const int c = 4 * ks + (lane >> 4);
-        return *reinterpret_cast<const __attribute__((address_space(3))) bf16x8*>(
-            (const __attribute__((address_space(3))) char*)(lds) + r * 128 + ((c ^ swz_rows(r)) << 4));
-    } else {
-        // lane 4q+p of each 16-lane group supplies the address of k-row q, columns 4p..4p+3;
-        // lane i of the group receives column i of the 4 k-rows (hardware transpose).
-        const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
-        const int k0 = 32 * ks + 8 * g + q, k1 = k0 + 4;
-        const int chunk = (rbase >> 3) + (p >> 1);
-        const int within = (p & 1) * 8;
-        const char* a0 = lds + k0 * (BR * 2) + ((chunk ^ swz_tr<BR>(k0)) << 4) + within;
-        const char* a1 = lds + k1 * (BR * 2) + ((chunk ^ swz_tr<BR>(k1)) << 4) + within;
-        bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)(a0));
-        bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bf16x4*)(a1));
-        return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-    }
-}
-
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // ------------------------------------------------------------------ the kernel
 // Two LDS slots; waits use a COUNTED vmcnt and raw s_barrier so that the refill DMA keeps flying across barriers
@@ -248,6 +175,7 @@ __global__ __launch_bounds__(256, LB) void gemm_kernel(const GemmGroup g) {
                 for (int j = 0; j < TN; ++j) bfr[ks][j] = read_frag<BN, BT>(slot + A_BYTES, wn * WN + 16 * j, ks, lane);
             }
             auto mfma_half = [&](int ks) {
+                if (g.dbg & 16) return;     // experiment: loads and barriers only
     #pragma unroll
                 for (int i = 0; i < TM; ++i)
     #pragma unroll
@@ -263,13 +191,13 @@ __global__ __launch_bounds__(256, LB) void gemm_kernel(const GemmGroup g) {
             if (it + 2 < nt) {
                 // own fragment reads retired, then the barrier: every wave is done with this slot -> refill it
                 asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-                stage_tile<BM, AT>(ra, m0, (t0 + it + 2) * BK, p.lda, slot, wave, lane);
-                stage_tile<BN, BT>(rb, n0, (t0 + it + 2) * BK, p.ldb, slot + A_BYTES, wave, lane);
+                if (!(g.dbg & 32)) stage_tile<BM, AT>(ra, m0, (t0 + it + 2) * BK, p.lda, slot, wave, lane);
+                if (!(g.dbg & (8 | 32))) stage_tile<BN, BT>(rb, n0, (t0 + it + 2) * BK, p.ldb, slot + A_BYTES, wave, lane);
             }
             mfma_half(1);
             if (it + 1 < nt) {
                 // K-step it+1 must have landed everywhere before the next iteration reads it; the refill just issued may fly on
-                if (it + 2 < nt) wait_vmcnt<DMA_PER_STAGE>(); else wait_vmcnt<0>();
+                if (it + 2 < nt && !(g.dbg & (8 | 32))) wait_vmcnt<DMA_PER_STAGE>(); else wait_vmcnt<0>();
                 asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             }
         }
@@ -512,6 +440,7 @@ static int tiles_for(const GemmProblem& p, int cfg) {
 }
 
 int gemm_pick_tile(const GemmProblem* probs, int nprob, int tile_cfg) {
+    if (tile_cfg == 6 || tile_cfg == 7) return tile_cfg - 6;     // the persistent kernel: 128x128 / 128x64 tiles
     if (tile_cfg >= 0) return tile_cfg;
     // Measured on MI355X (profiles/r01_b_microbench.json): a workgroup's speed is set by its L2->LDS fill
     // rate (~70 GB/s per CU), so the big tile (64 FLOP/B) wins once it alone covers the 256 CUs ~1.5x;
@@ -600,11 +529,12 @@ static int launch_stages(const GemmGroup& g, GemmLayout layout, int stages, int 
 int gemm_pick_stages(int, GemmLayout, int, int stages) { return (stages == 3 || stages == 4) ? stages : 2; }
 
 int launch_gemm_big_nt(const GemmProblem& p, int cfg, hipStream_t stream);   // gemm_big.hip (experiments: tile configs 3-5)
+int launch_gemm_persist(const GemmGroup& g, GemmLayout layout, int cfg, hipStream_t stream);   // gemm_persist.hip; 1 = not eligible
 
 int launch_gemm(const GemmProblem* probs, int nprob, GemmLayout layout, int tile_cfg, hipStream_t stream, int stages) {
     BVC_REQUIRE(nprob >= 1 && nprob <= kMaxGroup, "launch_gemm: nprob %d out of range", nprob);
-    if (tile_cfg >= 3) {
-        BVC_REQUIRE(tile_cfg <= 5 && nprob == 1 && layout == GEMM_NT, "launch_gemm: tile configs 3-5 (32-deep K steps) are NT, one problem");
+    if (tile_cfg >= 3 && tile_cfg <= 5) {
+        BVC_REQUIRE(nprob == 1 && layout == GEMM_NT, "launch_gemm: tile configs 3-5 (32-deep K steps) are NT, one problem");
         return launch_gemm_big_nt(probs[0], tile_cfg, stream);
     }
     const int cfg = gemm_pick_tile(probs, nprob, tile_cfg);
@@ -637,6 +567,18 @@ int launch_gemm(const GemmProblem* probs, int nprob, GemmLayout layout, int tile
     int kmax = 0;
     for (int i = 0; i < nprob; ++i) kmax = probs[i].K > kmax ? probs[i].K : kmax;
     const int ns = gemm_pick_stages(cfg, layout, kmax, stages);
+    // short-K single products with many tile rounds go to the persistent kernel (tile config 6 forces it, for tests);
+    // BVC_GEMM_NO_PERSIST=1 keeps them on gemm_kernel (same-process A/B)
+    // Same-box A/B at B=64 (profiles/r01_f_persist_ab_b64.txt): 128x128 persistent -12 ... -15 % on every eligible product; the
+    // 128x64 form wins only at short K (decoder proj, K=384: -5 %) and LOSES 6-16 % at K >= 1152, where the per-tile kernel's
+    // third resident workgroup per CU matters more than the chaining - so it is taken up to K = 512 only.
+    const bool auto_persist = tile_cfg < 0 && stages < 3 && g.dbg == 0 && (cfg == 0 || (cfg == 1 && probs[0].K <= 512)) &&
+                              getenv("BVC_GEMM_NO_PERSIST") == nullptr;
+    if (nprob == 1 && (tile_cfg >= 6 || auto_persist)) {
+        const int rc = launch_gemm_persist(g, layout, cfg, stream);
+        if (rc != 1) return rc;
+        BVC_REQUIRE(tile_cfg < 6, "launch_gemm: tile configs 6 / 7 (persistent 128x128 / 128x64) do not take this problem");
+    }
     switch (cfg) {
         case 0: return launch_stages<128, 128>(g, layout, ns, total, stream);
         case 1: return launch_stages<128, 64>(g, layout, ns, total, stream);

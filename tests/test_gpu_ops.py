@@ -5,6 +5,7 @@ product of the same bf16-rounded inputs; tolerances are written next to each che
 Integer/index kernels (mask -> token lists, patch gather) are bit-exact.
 """
 import math
+import os
 
 import numpy as np
 import pytest
@@ -502,3 +503,66 @@ def test_fused_adamw_with_gradscaler_skips_on_inf():
     torch.cuda.synchronize()
     assert torch.equal(p.detach(), before) and float(opt.state[p]["step"]) == 1.0     # skipped: nothing moved, step not advanced
     assert scaler.get_scale() == 32.0
+
+
+# --------------------------------------------------------------------------- persistent GEMM (gemm_persist.hip)
+@pytest.mark.parametrize("layout", [G.NT, G.NN])
+@pytest.mark.parametrize("epi", ["F32", "BF16", "GELU", "RESID", "DGELU", "F32_BF16"])
+@pytest.mark.parametrize("M,N,K,tile", [(5120, 3328, 128, 0), (5000, 3336, 384, 0), (13000, 1288, 192, 0), (4224, 4096, 1024, 0),
+                                          (25000, 384, 192, 1), (9000, 1032, 128, 1), (20000, 392, 1536, 1)])
+def test_gemm_persistent_matches_the_per_tile_kernel(layout, epi, M, N, K, tile):
+    """The persistent 128x128 kernel (tile config 6: one workgroup walks a sequence of tiles, the next tile's first K steps are
+    prefetched under the current tile's tail and epilogue) against gemm_kernel (tile config 0) on the same operands: same tile
+    walk and fragment order, so the results must be bit-identical; ragged M / N edges, odd and even numbers of K steps, and
+    more tiles than two rounds of the 512 resident workgroups.  Checked against torch as well."""
+    sa, sb = _shapes(layout, M, N, K)
+    A, B = G.bf16_randn(*sa, seed=21), G.bf16_randn(*sb, seed=22)
+    bias = torch.randn(N, device=dev)
+    out_f32 = epi in ("F32", "RESID", "F32_BF16")
+    res = []
+    for tile in (tile, tile + 6):      # per-tile kernel, then the persistent kernel with the same tile shape
+        C = torch.full((M, N), float("nan"), device=dev, dtype=torch.float32 if out_f32 else torch.bfloat16)
+        kw = dict(bias=bias)
+        extra = None
+        if epi in ("GELU", "F32_BF16"):
+            extra = torch.full((M, N), float("nan"), device=dev, dtype=torch.bfloat16)
+            kw["C2"] = extra
+        if epi == "RESID":
+            kw["resid"] = torch.randn(M, N, generator=torch.Generator().manual_seed(23)).to(dev)
+        if epi == "DGELU":
+            kw = dict(aux=G.bf16_randn(M, N, seed=24))
+        G.run_gemm([G.gemm_desc(A, B, M, N, K, G.EPI[epi], C, alpha=0.5, **kw)], layout, tile)
+        torch.cuda.synchronize()
+        res.append((C, extra, kw))
+    (c0, e0, kw), (c6, e6, _) = res
+    assert torch.isfinite(c6.float()).all()
+    assert torch.equal(c0, c6), float((c0.float() - c6.float()).abs().max())
+    if e0 is not None:
+        assert torch.equal(e0, e6)
+    ref = 0.5 * _ref_gemm(A, B, layout)
+    if epi == "DGELU":
+        x = kw["aux"].float()
+        ref = ref * (0.5 * (1 + torch.erf(x / math.sqrt(2))) + x * torch.exp(-0.5 * x * x) / math.sqrt(2 * math.pi))
+    else:
+        ref = ref + bias
+    if epi == "RESID":
+        ref = ref + kw["resid"]
+    assert G.rel_err(c6.float(), ref) < (1e-5 if out_f32 else 4e-3)
+
+
+def test_gemm_persistent_is_the_default_for_eligible_products():
+    """Auto tile selection must route a decoder-shaped product through the persistent kernel and give the same bits as the
+    per-tile kernel forced by BVC_GEMM_NO_PERSIST (the same-process A/B switch)."""
+    M, N, K = 25088, 1152, 384
+    A, B = G.bf16_randn(M, K, seed=31), G.bf16_randn(N, K, seed=32)
+    outs = []
+    for env in (None, "1"):
+        if env:
+            os.environ["BVC_GEMM_NO_PERSIST"] = env
+        C = torch.zeros(M, N, device=dev, dtype=torch.bfloat16)
+        G.run_gemm([G.gemm_desc(A, B, M, N, K, G.EPI["BF16"], C)], G.NT, -1)
+        torch.cuda.synchronize()
+        os.environ.pop("BVC_GEMM_NO_PERSIST", None)
+        outs.append(C)
+    assert torch.equal(outs[0], outs[1])
+    assert G.rel_err(outs[0].float(), _ref_gemm(A, B, G.NT)) < 4e-3

@@ -13,7 +13,7 @@ from tools.microbench import timeit  # noqa: E402
 dev = "cuda"
 lines = []
 M = int(os.environ.get("BVC_BATCH", "64")) * 1568
-for N, K, layout, epi in ((1152, 384, G.NT, "BF16"), (1536, 384, G.NT, "GELU"), (1536, 384, G.NN, "DGELU"), (384, 1536, G.NN, "BF16"),
+for N, K, layout, epi in ((1152, 384, G.NT, "BF16"), (1152, 1536, G.NT, "BF16"), (1536, 384, G.NT, "GELU"), (384, 1536, G.NN, "BF16"),
                           (1152, 64, G.NT, "BF16")):
     A = G.bf16_randn(M, K)
     B = G.bf16_randn(N, K) if layout == G.NT else G.bf16_randn(K, N)
@@ -25,11 +25,12 @@ for N, K, layout, epi in ((1152, 384, G.NT, "BF16"), (1536, 384, G.NT, "GELU"), 
         kw = dict(aux=G.bf16_randn(M, N, seed=3))
     d = G.gemm_desc(A, B, M, N, K, G.EPI[epi], C, **kw)
     row = []
-    for dbg in (0, 1, 2, 3):
+    for dbg in (0, 1, 1 + 8, 1 + 32, 1 + 16, 1 + 16 + 32, 16):
         os.environ["BVC_GEMM_DEBUG"] = str(dbg)
         row.append(timeit(lambda: G.run_gemm([d], layout, 0, -1), iters=10, warm=2) * 1e3)
     os.environ.pop("BVC_GEMM_DEBUG", None)
-    s = f"M={M} N={N} K={K} {['NT','NN','TN'][layout]} {epi:5s}: normal {row[0]:.0f}us | no bf16 stores {row[1]:.0f}us | staggered {row[2]:.0f}us | both {row[3]:.0f}us"
+    s = (f"M={M} N={N} K={K} {['NT','NN','TN'][layout]} {epi:5s}: normal {row[0]:.0f}us | no stores {row[1]:.0f} | no stores, A refills only {row[2]:.0f} | "
+         f"no stores, no refills {row[3]:.0f} | no stores, no MFMA {row[4]:.0f} | no stores/MFMA/refills {row[5]:.0f} | no MFMA (loads + stores) {row[6]:.0f}")
     print(s, flush=True)
     lines.append(s)
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)

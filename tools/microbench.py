@@ -86,12 +86,12 @@ def main():
                 best = r
             if tile < 0:
                 auto = r
-        os.environ["BVC_GEMM_LEGACY_WALK"] = "1"      # same-run A/B of the L2-aware tile walk (gemm.hip: pick_panel)
+        os.environ["BVC_GEMM_NO_PERSIST"] = "1"      # same-run A/B: per-tile kernel instead of the persistent one
         legacy = gemm_case(name, lay, M, N, K, -1, split, epi, -1)
-        os.environ.pop("BVC_GEMM_LEGACY_WALK", None)
-        legacy["walk"] = "legacy"
+        os.environ.pop("BVC_GEMM_NO_PERSIST", None)
+        legacy["walk"] = "per-tile"
         out.append(legacy)
-        line = f"{name:12s} auto {auto['ms']*1e3:7.1f}us {auto['tflops']:6.1f}TF | legacy walk {legacy['ms']*1e3:7.1f}us {legacy['tflops']:6.1f}TF"
+        line = f"{name:12s} auto {auto['ms']*1e3:7.1f}us {auto['tflops']:6.1f}TF | per-tile kernel {legacy['ms']*1e3:7.1f}us {legacy['tflops']:6.1f}TF"
         if best:
             line += f" | best tile{best['tile']} st{best['stages']} {best['ms']*1e3:7.1f}us {best['tflops']:6.1f}TF"
         print(line, flush=True)

@@ -451,7 +451,9 @@ int gemm_pick_tile(const GemmProblem* probs, int nprob, int tile_cfg) {
         t1 += tiles_for(probs[i], 1) * probs[i].split_k;
         nmax = probs[i].N > nmax ? probs[i].N : nmax;
     }
-    if (nmax <= 384) return t1 >= 256 ? 1 : 2;
+    // ... unless there are at least two full rounds of 128x128 tiles anyway (B >= ~40 decoder shapes): then the big tile is as
+    // fast at K = 384 and 15 % faster at K = 1536 (profiles/r01_e_gemm_ksweep_b64.txt, N = 384 rows), and it can be chained
+    if (nmax <= 384) return t0 >= 1024 ? 0 : (t1 >= 256 ? 1 : 2);
     if (t0 >= 400) return 0;
     if (t1 >= 400) return 1;
     return 2;

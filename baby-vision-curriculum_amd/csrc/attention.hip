@@ -276,35 +276,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
     }
 }
 
-// ============================================================================ delta = rowsum(dO * O)
-// one thread per (row, head, 8-column chunk); HD/8 lanes per (row, head)
-template <int HD>
-__global__ void attn_delta_kernel(const bf16_t* __restrict__ dctx, const bf16_t* __restrict__ ctx,
-                                  float* __restrict__ delta, int B, int N, int H, int D) {
-    constexpr int PCS = HD / 8;
-    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long long total = (long long)B * N * H * PCS;
-    float acc = 0.f;
-    long long item = gid / PCS;
-    const int piece = (int)(gid % PCS);
-    if (gid < total) {
-        const long long row = item / H;
-        const int head = (int)(item % H);
-        const size_t off = (size_t)row * D + head * HD + piece * 8;
-        const bf16x8 a = load8(dctx + off), o = load8(ctx + off);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc += bf2f((bf16_t)a[j]) * bf2f((bf16_t)o[j]);
-    }
-#pragma unroll
-    for (int o = 1; o < PCS; o <<= 1) acc += __shfl_xor(acc, o, 64);
-    if (gid < total && piece == 0) {
-        const long long row = item / H;
-        const int head = (int)(item % H);
-        const int b = (int)(row / N), q = (int)(row % N);
-        delta[((size_t)b * H + head) * N + q] = acc;
-    }
-}
-
 // ============================================================================ dQ
 template <int HD, int KOFF, int VOFF>
 __device__ __forceinline__ void dq_subtile(const AS3 char* lds, const FragAddr<HD>& fa, const bf16x8 (&qf)[HD / 16],
@@ -336,8 +307,8 @@ __device__ __forceinline__ void dq_subtile(const AS3 char* lds, const FragAddr<H
 // grid (ceil(N/128), B*H); wave w owns 32 queries; loops over key tiles (K and V staged)
 template <int HD>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dctx,
-                                                             const float* __restrict__ lse, const float* __restrict__ delta,
-                                                             bf16_t* __restrict__ dqkv, int N, int H, int D,
+                                                             const bf16_t* __restrict__ ctx, const float* __restrict__ lse,
+                                                             float* __restrict__ delta, bf16_t* __restrict__ dqkv, int N, int H, int D,
                                                              uint32_t qkv_bytes, float scale, float scale_log2, int remap) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int IMG = 64 * HD * 2, STG = 2 * IMG, SUB = 32 * HD * 2;
@@ -355,14 +326,25 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
     const FragAddr<HD> fa = make_frag_addr<HD>(lane);
 
     bf16x8 qf[HD / 16], dof[HD / 16];
+    float del_q = 0.f;
     {
         const bf16_t* qrow = qkv + (size_t)(b * N + qc) * ld + head * HD + 8 * h;
         const bf16_t* drow = dctx + (size_t)(b * N + qc) * D + head * HD + 8 * h;
+        const bf16_t* orow_in = ctx + (size_t)(b * N + qc) * D + head * HD + 8 * h;
 #pragma unroll
-        for (int st = 0; st < HD / 16; ++st) { qf[st] = load8(qrow + 16 * st); dof[st] = load8(drow + 16 * st); }
+        for (int st = 0; st < HD / 16; ++st) {
+            qf[st] = load8(qrow + 16 * st);
+            dof[st] = load8(drow + 16 * st);
+            // delta = rowsum(dO * O) of this query (the softmax-gradient correction): the two half-waves hold disjoint halves
+            // of the row, so it costs one more 16-B load per step here instead of a pass of its own over dO and O
+            const bf16x8 of = load8(orow_in + 16 * st);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) del_q += bf2f((bf16_t)dof[st][j]) * bf2f((bf16_t)of[j]);
+        }
     }
+    del_q += __shfl_xor(del_q, 32, 64);
+    if (h == 0 && qi < N) delta[(size_t)bh * N + qi] = del_q;      // the dK/dV kernel, launched after this one, reads it
     const float nlse = -lse[(size_t)bh * N + qc];
-    const float del_q = delta[(size_t)bh * N + qc];
     f32x16 dq[HD / 32];
 #pragma unroll
     for (int t = 0; t < HD / 32; ++t) dq[t] = zero16();
@@ -547,16 +529,13 @@ static int bwd_hd(const bf16_t* qkv, const bf16_t* ctx, const bf16_t* dctx, cons
     const int D = H * HD;
     const size_t bytes = (size_t)B * N * 3 * D * 2;
     const float scale = sm_scale > 0.f ? sm_scale : 1.0f / sqrtf((float)HD), scale_log2 = scale * 1.4426950408889634f;
-    {
-        const long long total = (long long)B * N * H * (HD / 8);
-        hipLaunchKernelGGL(attn_delta_kernel<HD>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, dctx, ctx, delta, B, N, H, D);
-    }
     const dim3 grid((unsigned)(((N + 127) / 128) * B * H));
     const int remap = xcd_remap();
+    // dQ first: it also produces delta = rowsum(dO * O), which the dK/dV kernel consumes
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<HD>, grid, dim3(256), 4 * 64 * HD * 2, stream, qkv, dctx, ctx, lse, delta, dqkv, N, H, D,
+                       (uint32_t)bytes, scale, scale_log2, remap);
     hipLaunchKernelGGL(attn_bwd_dkdv_kernel<HD>, grid, dim3(256), 2 * (2 * 64 * HD * 2 + 512), stream, qkv, dctx, lse, delta, dqkv, N, H, D,
                        (uint32_t)bytes, (uint32_t)((size_t)B * N * D * 2), (uint32_t)((size_t)B * H * N * 4), scale, scale_log2, remap);
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<HD>, grid, dim3(256), 4 * 64 * HD * 2, stream, qkv, dctx, lse, delta, dqkv, N, H, D,
-                       (uint32_t)bytes, scale, scale_log2, remap);
     BVC_CHECK_HIP(hipGetLastError());
     return BVC_OK;
 }

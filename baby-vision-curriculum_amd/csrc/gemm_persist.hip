@@ -110,11 +110,13 @@ __global__ __launch_bounds__(256, 2) void gemm_persist_kernel(const GemmGroup g)
                 for (int j = 0; j < TN; ++j) bfr[ks][j] = read_frag<BN, BT>(slot + A_BYTES, wn * WN + 16 * j, ks, lane);
             }
             auto mfma_half = [&](int ks) {
+                if (g.dbg & 64) __builtin_amdgcn_s_setprio(1);      // experiment: raised priority over the MFMA burst
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ks][j], af[ks][i], acc[i][j], 0, 0, 0);
+                if (g.dbg & 64) __builtin_amdgcn_s_setprio(0);
             };
             mfma_half(0);
             // this slot is refilled with K step it + 2 of the stream: of this tile, or of the next one

@@ -1,33 +1,15 @@
-"""Loss all-reduce with the reference's semantics (pretraining/generative/ddputils.py:53-68):
-forward = mean over ranks (x / world, then all-reduce SUM), backward = identity."""
-import torch
-import torch.distributed as dist
-
-
-def is_dist():
-    return dist.is_available() and dist.is_initialized()
-
-
-def get_world_size():
-    return dist.get_world_size() if is_dist() else 1
+"""Process-group helpers under the names the generative entry point imports (pretraining/generative/ddputils.py is where
+pretrain_videomae.py:301-304 takes ``AllReduce`` from); the implementations live in ``distributed.py``."""
+from .distributed import AllReduce, world  # noqa: F401
 
 
 def get_rank():
-    return dist.get_rank() if is_dist() else 0
+    return world()[0]
+
+
+def get_world_size():
+    return world()[1]
 
 
 def is_main_process():
-    return get_rank() == 0
-
-
-class AllReduce(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, x):
-        if is_dist() and dist.get_world_size() > 1:
-            x = x.contiguous() / dist.get_world_size()
-            dist.all_reduce(x)
-        return x
-
-    @staticmethod
-    def backward(ctx, grads):
-        return grads
+    return world()[0] == 0

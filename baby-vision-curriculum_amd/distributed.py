@@ -1,55 +1,79 @@
-"""Collective autograd functions with the reference's semantics (pretraining/predictive/distributed.py:49-112).
-``AllGather`` is what the global-batch SimCLR loss (BASELINE config 5) needs: forward = all_gather + cat on dim 0,
-backward = all_reduce(grads) then the rank's own slice.  torch.distributed's "nccl" backend is RCCL on ROCm."""
+"""Collectives of the training step as autograd nodes, over torch.distributed ("nccl" = RCCL on ROCm, gloo on CPU).
+
+What the reference's entry points expect from them (interfaces only; the bodies below are this package's):
+  AllReduce     pretraining/generative/ddputils.py:53-68, pretraining/predictive/distributed.py:96-112
+                value -> mean over ranks, gradient passes through unchanged (the logged loss is global, the step is local)
+  AllReduceSum  pretraining/predictive/distributed.py:79-93   value -> sum over ranks, gradient unchanged
+  AllGather     pretraining/predictive/distributed.py:49-76   rows of every rank stacked on dim 0; backward sums the
+                incoming gradient over ranks and keeps the rows this rank contributed (needed by BASELINE config 5)
+With one process (or no process group) every node is the identity, so single-GPU scripts need no branches.
+"""
 import torch
 import torch.distributed as dist
 
 
-def _on():
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+def world():
+    """(rank, size) of the default group; (0, 1) when torch.distributed is not in use."""
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def _reduced(t, scale):
+    """Sum of `t * scale` over all ranks, as a new tensor (the collective works in place on a private copy)."""
+    buf = (t * scale).contiguous() if scale != 1.0 else t.contiguous().clone()
+    dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+    return buf
+
+
+class _PassThroughBackward(torch.autograd.Function):
+    """Base of the two loss reductions: backward hands the incoming gradient on untouched."""
+    scale_by_world = False
+
+    @classmethod
+    def _forward_value(cls, x):
+        _, n = world()
+        if n == 1:
+            return x
+        return _reduced(x, 1.0 / n if cls.scale_by_world else 1.0)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        return grad_output
+
+
+class AllReduce(_PassThroughBackward):
+    scale_by_world = True
+
+    @staticmethod
+    def forward(ctx, x):
+        return AllReduce._forward_value(x)
+
+
+class AllReduceSum(_PassThroughBackward):
+    scale_by_world = False
+
+    @staticmethod
+    def forward(ctx, x):
+        return AllReduceSum._forward_value(x)
 
 
 class AllGather(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):
-        if _on():
-            x = x.contiguous()
-            out = torch.empty((dist.get_world_size() * x.shape[0],) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
-            dist.all_gather_into_tensor(out, x)       # one contiguous buffer: no list of tensors + cat copy
-            return out
-        return x
+        rank, n = world()
+        ctx.span = (rank * x.shape[0], x.shape[0], n)
+        if n == 1:
+            return x
+        src = x.contiguous()
+        out = src.new_empty((n * src.shape[0],) + tuple(src.shape[1:]))
+        dist.all_gather_into_tensor(out, src)          # one contiguous destination: no list of pieces, no cat
+        return out
 
     @staticmethod
-    def backward(ctx, grads):
-        if _on():
-            n = grads.shape[0] // dist.get_world_size()
-            grads = grads.contiguous()
-            dist.all_reduce(grads)
-            return grads[n * dist.get_rank(): n * (dist.get_rank() + 1)]
-        return grads
-
-
-class AllReduceSum(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, x):
-        if _on():
-            x = x.contiguous()
-            dist.all_reduce(x)
-        return x
-
-    @staticmethod
-    def backward(ctx, grads):
-        return grads
-
-
-class AllReduce(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, x):
-        if _on():
-            x = x.contiguous() / dist.get_world_size()
-            dist.all_reduce(x)
-        return x
-
-    @staticmethod
-    def backward(ctx, grads):
-        return grads
+    def backward(ctx, grad_output):
+        start, rows, n = ctx.span
+        if n == 1:
+            return grad_output
+        total = _reduced(grad_output, 1.0)
+        return total.narrow(0, start, rows)

@@ -1,129 +1,94 @@
-"""Host-side multi-block mask sampler with the reference's interface (pretraining/predictive/mask.py).
+"""Host-side multi-block mask sampler for the JEPA step, with the interface of pretraining/predictive/mask.py
+(``MaskCollator(...)`` used as the DataLoader ``collate_fn``, ``update_masks``; pretrain_jepa.py:226-235,329-340).
 
-Stays PyTorch CPU code, used as the DataLoader ``collate_fn`` exactly like the reference (pretrain_jepa.py:226-235,
-329-340): one seeded draw of the block sizes per step (shared counter across workers), unseeded draws of the block
-positions, enc masks constrained to the complement of the pred blocks, every mask truncated to the batch minimum.
+It has to reproduce the reference's random stream to reproduce its masks (fixture: tests/golden/jepa.json,
+``mask_collator``): per call one generator seeded with a counter shared by all loader workers yields the target-block and
+context-block shapes (one uniform draw each); block corners then come from the GLOBAL torch generator, row before column,
+target blocks of a sample first, then its context blocks, redrawing while a block keeps too few tokens.  Everything else
+(how rectangles, keep-lists and the batch tensors are built) is this package's own.
 """
 import math
 from logging import getLogger
 from multiprocessing import Value
 
 import torch
+from torch.utils.data import default_collate
 
 logger = getLogger()
 
 
 def update_masks(masks, image_size, patch_size, num_frames, tubelet_size, isencoder=False):
-    """mask.py:21-38: spatial indices -> spatio-temporal ones; context from temporal slot 0, targets from the last slot."""
-    T = num_frames // tubelet_size
-    num_patches_per_frame = (image_size // patch_size) ** 2
-    for i_mask, m in enumerate(masks):
-        frame_index = 0 if isencoder else T - 1
-        m += frame_index * num_patches_per_frame
-        masks[i_mask] = m
+    """Spatial token indices -> indices into the (T, H, W) token grid: context tokens live in temporal slot 0, target tokens
+    in the last slot.  Shifts the tensors in place (the caller keeps using the same list), like the reference."""
+    per_slot = (image_size // patch_size) ** 2
+    slot = 0 if isencoder else num_frames // tubelet_size - 1
+    for m in masks:
+        m += slot * per_slot
     return masks
 
 
 class MaskCollator(object):
-    """mask.py:69-219"""
-
     def __init__(self, input_size=(224, 224), patch_size=16, enc_mask_scale=(0.2, 0.8), pred_mask_scale=(0.2, 0.8),
                  aspect_ratio=(0.3, 3.0), nenc=1, npred=2, min_keep=4, allow_overlap=False):
-        super().__init__()
-        if not isinstance(input_size, tuple):
-            input_size = (input_size,) * 2
+        size = input_size if isinstance(input_size, tuple) else (input_size, input_size)
         self.patch_size = patch_size
-        self.height, self.width = input_size[0] // patch_size, input_size[1] // patch_size
-        self.enc_mask_scale = enc_mask_scale
-        self.pred_mask_scale = pred_mask_scale
-        self.aspect_ratio = aspect_ratio
-        self.nenc = nenc
-        self.npred = npred
-        self.min_keep = min_keep
-        self.allow_overlap = allow_overlap
-        self._itr_counter = Value('i', -1)   # shared across DataLoader worker processes
+        self.height, self.width = size[0] // patch_size, size[1] // patch_size
+        self.enc_mask_scale, self.pred_mask_scale, self.aspect_ratio = enc_mask_scale, pred_mask_scale, aspect_ratio
+        self.nenc, self.npred, self.min_keep, self.allow_overlap = nenc, npred, min_keep, allow_overlap
+        self._itr_counter = Value('i', -1)          # lives in shared memory: one sequence of seeds for all workers
 
     def step(self):
-        i = self._itr_counter
-        with i.get_lock():
-            i.value += 1
-            v = i.value
-        return v
+        with self._itr_counter.get_lock():
+            self._itr_counter.value += 1
+            return self._itr_counter.value
 
-    def _sample_block_size(self, generator, scale, aspect_ratio_scale):
-        _rand = torch.rand(1, generator=generator).item()
-        min_s, max_s = scale
-        mask_scale = min_s + _rand * (max_s - min_s)
-        max_keep = int(self.height * self.width * mask_scale)
-        min_ar, max_ar = aspect_ratio_scale
-        aspect_ratio = min_ar + _rand * (max_ar - min_ar)
-        h = int(round(math.sqrt(max_keep * aspect_ratio)))
-        w = int(round(math.sqrt(max_keep / aspect_ratio)))
-        while h >= self.height:
-            h -= 1
-        while w >= self.width:
-            w -= 1
-        return (h, w)
+    # ---- block shapes: ONE uniform number fixes both the area fraction and the aspect ratio of a block
+    def _block_shape(self, gen, area_range, ratio_range):
+        u = torch.rand(1, generator=gen).item()
+        area = int(self.height * self.width * (area_range[0] + u * (area_range[1] - area_range[0])))
+        ratio = ratio_range[0] + u * (ratio_range[1] - ratio_range[0])
+        rows = min(int(round(math.sqrt(area * ratio))), self.height - 1)
+        cols = min(int(round(math.sqrt(area / ratio))), self.width - 1)
+        return rows, cols
 
-    def _sample_block_mask(self, b_size, acceptable_regions=None):
-        h, w = b_size
-
-        def constrain_mask(mask, tries=0):
-            N = max(int(len(acceptable_regions) - tries), 0)
-            for k in range(N):
-                mask *= acceptable_regions[k]
-
-        tries = 0
-        timeout = og_timeout = 20
-        valid_mask = False
-        while not valid_mask:
-            top = torch.randint(0, self.height - h, (1,))
-            left = torch.randint(0, self.width - w, (1,))
-            mask = torch.zeros((self.height, self.width), dtype=torch.int32)
-            mask[top:top + h, left:left + w] = 1
-            if acceptable_regions is not None:
-                constrain_mask(mask, tries)
-            mask = torch.nonzero(mask.flatten())
-            valid_mask = len(mask) > self.min_keep
-            if not valid_mask:
-                timeout -= 1
-                if timeout == 0:
-                    tries += 1
-                    timeout = og_timeout
-                    logger.warning(f'Mask generator says: "Valid mask not found, decreasing acceptable-regions [{tries}]"')
-        mask = mask.squeeze()
-        mask_complement = torch.ones((self.height, self.width), dtype=torch.int32)
-        mask_complement[top:top + h, left:left + w] = 0
-        return mask, mask_complement
+    # ---- one block: corner from the global generator, kept tokens = the rectangle minus the forbidden cells
+    def _place_block(self, shape, forbidden=()):
+        rows, cols = shape
+        allowed = list(forbidden)                    # 0/1 grids the block may not leave (complements of the target blocks)
+        misses = 0
+        while True:
+            top = int(torch.randint(0, self.height - rows, (1,)))
+            left = int(torch.randint(0, self.width - cols, (1,)))
+            grid = torch.zeros((self.height, self.width), dtype=torch.bool)
+            grid[top:top + rows, left:left + cols] = True
+            for region in allowed:
+                grid &= region
+            kept = torch.nonzero(grid.reshape(-1)).reshape(-1)
+            if kept.numel() > self.min_keep:
+                outside = torch.ones((self.height, self.width), dtype=torch.bool)
+                outside[top:top + rows, left:left + cols] = False
+                return kept, outside
+            misses += 1
+            if misses % 20 == 0 and allowed:          # 20 failed corners: stop honouring the most recent target block
+                allowed.pop()
+                logger.warning("MaskCollator: no valid context block, relaxing the overlap constraint (%d regions left)", len(allowed))
 
     def __call__(self, batch):
-        B = len(batch)
-        collated_batch = torch.utils.data.default_collate(batch)
-        seed = self.step()
-        g = torch.Generator()
-        g.manual_seed(seed)
-        p_size = self._sample_block_size(generator=g, scale=self.pred_mask_scale, aspect_ratio_scale=self.aspect_ratio)
-        e_size = self._sample_block_size(generator=g, scale=self.enc_mask_scale, aspect_ratio_scale=(1., 1.))
-        collated_masks_pred, collated_masks_enc = [], []
-        min_keep_pred = self.height * self.width
-        min_keep_enc = self.height * self.width
-        for _ in range(B):
-            masks_p, masks_C = [], []
-            for _ in range(self.npred):
-                mask, mask_C = self._sample_block_mask(p_size)
-                masks_p.append(mask)
-                masks_C.append(mask_C)
-                min_keep_pred = min(min_keep_pred, len(mask))
-            collated_masks_pred.append(masks_p)
-            acceptable_regions = None if self.allow_overlap else masks_C
-            masks_e = []
-            for _ in range(self.nenc):
-                mask, _ = self._sample_block_mask(e_size, acceptable_regions=acceptable_regions)
-                masks_e.append(mask)
-                min_keep_enc = min(min_keep_enc, len(mask))
-            collated_masks_enc.append(masks_e)
-        collated_masks_pred = [[cm[:min_keep_pred] for cm in cm_list] for cm_list in collated_masks_pred]
-        collated_masks_pred = torch.utils.data.default_collate(collated_masks_pred)
-        collated_masks_enc = [[cm[:min_keep_enc] for cm in cm_list] for cm_list in collated_masks_enc]
-        collated_masks_enc = torch.utils.data.default_collate(collated_masks_enc)
-        return collated_batch, collated_masks_enc, collated_masks_pred
+        collated = default_collate(batch)
+        gen = torch.Generator()
+        gen.manual_seed(self.step())
+        target_shape = self._block_shape(gen, self.pred_mask_scale, self.aspect_ratio)
+        context_shape = self._block_shape(gen, self.enc_mask_scale, (1.0, 1.0))
+
+        targets, contexts = [], []                    # per sample: list of index tensors
+        for _ in range(len(batch)):
+            placed = [self._place_block(target_shape) for _ in range(self.npred)]
+            targets.append([kept for kept, _ in placed])
+            forbidden = () if self.allow_overlap else [outside for _, outside in placed]
+            contexts.append([self._place_block(context_shape, forbidden)[0] for _ in range(self.nenc)])
+
+        def to_batches(per_sample, count):
+            keep = min(t.numel() for sample in per_sample for t in sample)      # every row is cut to the shortest list
+            return [torch.stack([sample[k][:keep] for sample in per_sample]) for k in range(count)]
+
+        return collated, to_batches(contexts, self.nenc), to_batches(targets, self.npred)

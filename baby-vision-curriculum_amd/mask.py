@@ -1,48 +1,57 @@
-"""Host-side mask samplers with the reference's interface (pretraining/generative/mask.py).
+"""Host-side VideoMAE mask samplers with the interface of pretraining/generative/mask.py: ``Generator((T, H, W), ratio)()``
+returns a flat float64 vector of T*H*W zeros (visible) and ones (masked), which the step turns into a bool tensor
+(pretrain_videomae.py:294-298).
 
-numpy on the host, exactly like the reference: the step consumes the result as a bool tensor
-(pretrain_videomae.py:294-298).  An optional ``rng`` makes a run reproducible; with ``rng=None`` the
-global numpy RNG is used, as in the reference (which never seeds it).
+The draws follow the reference's random stream (one in-place ``shuffle`` of a "visible first, masked last" vector per call)
+so that a seeded run reproduces its masks; ``rng`` selects a private ``numpy.random.RandomState`` instead of the global one
+the reference uses.  Fixture: tests/golden/tube_mask.json.
 """
 import numpy as np
 
 
+def _shuffled_flags(count, masked, rng):
+    """`count` flags, the last `masked` of them set, permuted in place by the chosen generator."""
+    flags = (np.arange(count) >= count - masked).astype(np.float64)
+    (np.random if rng is None else rng).shuffle(flags)
+    return flags
+
+
 class TubeMaskingGenerator:
-    """Same spatial mask in every temporal slot (reference mask.py:3-24)."""
+    """One spatial mask per clip, repeated over every temporal slot (a "tube")."""
 
     def __init__(self, input_size, mask_ratio, rng=None):
-        self.frames, self.height, self.width = input_size
-        self.num_patches_per_frame = self.height * self.width
-        self.total_patches = self.frames * self.num_patches_per_frame
-        self.num_masks_per_frame = int(mask_ratio * self.num_patches_per_frame)
-        self.total_masks = self.frames * self.num_masks_per_frame
+        slots, rows, cols = input_size
+        self.slots, self.per_slot = slots, rows * cols
+        self.masked_per_slot = int(mask_ratio * self.per_slot)
         self.rng = rng
 
+    @property
+    def total_patches(self):
+        return self.slots * self.per_slot
+
+    @property
+    def total_masks(self):
+        return self.slots * self.masked_per_slot
+
     def __repr__(self):
-        return "Maks: total patches {}, mask patches {}".format(self.total_patches, self.total_masks)
+        return f"TubeMaskingGenerator({self.total_masks} of {self.total_patches} tokens masked)"
 
     def __call__(self):
-        per_frame = np.hstack([np.zeros(self.num_patches_per_frame - self.num_masks_per_frame),
-                               np.ones(self.num_masks_per_frame)])
-        (self.rng if self.rng is not None else np.random).shuffle(per_frame)
-        return np.tile(per_frame, (self.frames, 1)).flatten()
+        spatial = _shuffled_flags(self.per_slot, self.masked_per_slot, self.rng)
+        return np.broadcast_to(spatial, (self.slots, self.per_slot)).reshape(-1).copy()
 
 
 class RandomMaskingGenerator:
-    """Independent mask over all tokens (reference mask.py:26-46)."""
+    """Independent mask over all T*H*W tokens."""
 
     def __init__(self, input_size, mask_ratio, rng=None):
-        if not isinstance(input_size, tuple):
-            input_size = (input_size,) * 3
-        self.frames, self.height, self.width = input_size
-        self.num_patches = self.frames * self.height * self.width
+        dims = input_size if isinstance(input_size, tuple) else (input_size,) * 3
+        self.num_patches = int(np.prod(dims))
         self.num_mask = int(mask_ratio * self.num_patches)
         self.rng = rng
 
     def __repr__(self):
-        return "Maks: total patches {}, mask patches {}".format(self.num_patches, self.num_mask)
+        return f"RandomMaskingGenerator({self.num_mask} of {self.num_patches} tokens masked)"
 
     def __call__(self):
-        mask = np.hstack([np.zeros(self.num_patches - self.num_mask), np.ones(self.num_mask)])
-        (self.rng if self.rng is not None else np.random).shuffle(mask)
-        return mask
+        return _shuffled_flags(self.num_patches, self.num_mask, self.rng)

@@ -78,7 +78,7 @@ def test_mask_generators_match_reference_fixture(bvc, golden_dir):
     fx = json.load(open(os.path.join(golden_dir, "tube_mask.json")))
     for c in fx["cases"]:
         gen = bvc.TubeMaskingGenerator(tuple(c["grid"]), c["ratio"], rng=np.random.RandomState(c["seed"]))
-        assert gen.num_masks_per_frame == c["num_masks_per_frame"] and gen.total_masks == c["total_masks"]
+        assert gen.masked_per_slot == c["num_masks_per_frame"] and gen.total_masks == c["total_masks"]
         per = c["grid"][1] * c["grid"][2]
         for vis in c["visible_frame0"]:
             m = gen()

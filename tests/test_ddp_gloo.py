@@ -75,8 +75,19 @@ def _worker(rank, world, port, q):
     sl = slice(2 * rank, 2 * rank + 2)
     loss = model.step(pixels[sl], mask[sl])
     # loss all-reduce with the reference's semantics (ddputils.py:53-68)
-    mean_loss = ge.load_package().AllReduce.apply(loss.clone())
-    q.put((rank, model.grad.clone(), float(mean_loss), list(ddp.reduced_ranges)))
+    bvc = ge.load_package()
+    mean_loss = bvc.AllReduce.apply(loss.clone())
+    # AllGather (pretraining/predictive/distributed.py:49-76): rows of every rank stacked in rank order; backward = the incoming
+    # gradient summed over ranks, own rows kept.  AllReduceSum: value summed, gradient passed through.
+    x = (torch.arange(6, dtype=torch.float32).view(3, 2) + 10 * rank).requires_grad_(True)
+    y = bvc.distributed.AllGather.apply(x)
+    w = torch.arange(1, 1 + y.numel(), dtype=torch.float32).view_as(y)
+    (y * w).sum().backward()
+    s = torch.tensor(float(rank + 1), requires_grad=True)
+    t = bvc.distributed.AllReduceSum.apply(s * 3)
+    t.backward()
+    extra = {"gathered": y.detach().clone(), "gather_grad": x.grad.clone(), "w": w, "sum": float(t), "sum_grad": float(s.grad)}
+    q.put((rank, model.grad.clone(), float(mean_loss), list(ddp.reduced_ranges), extra))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -100,7 +111,11 @@ def test_two_rank_gradient_average_matches_global_batch():
     pixels, mask = vo.synthetic_batch(cfg, 4, seed=5, mask_ratio=0.75)
     loss, grads = vo.step(cfg, params, pixels, mask)          # single process, global batch
     ref = torch.cat([grads[k].reshape(-1) for k in params])
-    for rank, g, ml, ranges in got:
+    for rank, g, ml, ranges, extra in got:
+        want = torch.cat([torch.arange(6, dtype=torch.float32).view(3, 2) + 10 * r for r in range(world)])
+        assert torch.equal(extra["gathered"], want)
+        assert torch.equal(extra["gather_grad"], world * extra["w"][3 * rank:3 * rank + 3])
+        assert extra["sum"] == 3.0 * sum(r + 1 for r in range(world)) and extra["sum_grad"] == 3.0
         assert float((g - ref).norm() / ref.norm()) < 1e-5, rank
         assert abs(ml - float(loss)) / float(loss) < 1e-6
         # ranges were coalesced into buckets, arrive tail-first and tile the buffer exactly once

@@ -1,22 +1,27 @@
-// bf16 x bf16 -> f32 MFMA GEMM for gfx950 (MI355X), with the fused epilogues the ViT step needs.
+// bf16 x bf16 -> f32 MFMA GEMM for gfx950 (MI355X), with the fused epilogues the ViT step needs: the per-tile kernel
+// (every output tile is one workgroup) and the host-side launcher / tile planner.  gemm_persist.hip holds the persistent form
+// that chains tiles for the short-K products; gemm_tile.h the staging / fragment helpers both share.
 //
 // Structure (per 256-thread workgroup = 4 waves as 2x2, 64-deep K steps):
 //   * A and B tiles go HBM -> LDS directly with `buffer_load_dwordx4 ... lds` (LDS-DMA, 1 KiB per
 //     wave-instruction).  The buffer descriptor's bounds check returns zeros for rows past the end of
 //     the allocation, which is how ragged M / ragged contraction lengths are handled - no host padding.
-//   * two LDS stages; the DMA for K-step t+1 is issued right after the barrier that publishes step t,
-//     so it flies under step t's MFMAs (one barrier per K step).
+//   * two LDS slots, "early refill": a wave pulls all fragments of the current K step into registers, a barrier proves
+//     the slot drained, the slot is refilled with K step t+2 and only then do the MFMAs run - two K steps of DMA are in
+//     flight under the MFMAs; waits are counted (`s_waitcnt vmcnt(N)`) and barriers raw, so the DMA flies across them.
 //   * LDS images are XOR-swizzled on the 16-byte chunk index.  LDS-DMA writes lane-linear, so the
 //     swizzle is applied to the per-lane SOURCE address and again on the read (both sides or neither).
 //   * k-contiguous operands are read with ds_read_b128; operands whose contraction index is the
 //     strided one (dX = dY W, dW = dY^T X) stay in their natural layout in HBM and LDS and are
 //     transposed on the LDS read by ds_read_b64_tr_b16 - no transposed copies of weights or activations.
 //   * v_mfma_f32_16x16x32_bf16 with the operands swapped, so each lane ends up with 4 consecutive
-//     output columns of one row: epilogue loads/stores are 8-16 B per lane.
-//   * block index -> tile mapping is XCD-aware (blocks b and b+8 share an XCD/L2): each XCD gets a
-//     contiguous run of tiles, consecutive tiles share the A row panel.
+//     output columns of one row; the epilogue parks the f32 tile in LDS and re-reads it row-major so that every global
+//     load / store is a full 128-B line per 8 lanes, and fetches all its side inputs before its first store (loads and
+//     stores retire through one in-order counter).
+//   * block index -> tile mapping is XCD-aware (blocks b and b+8 share an XCD/L2): each XCD gets a contiguous run of
+//     tiles, walked in column panels sized for its L2 (NT / NN) or along the short side with K-splits fastest (TN).
 //   * up to 4 independent problems per launch (grouped GEMM) to fill 256 CUs with the small
-//     weight-gradient products of one transformer layer.
+//     weight-gradient products of one transformer layer; split-K with f32 atomics; fused bias gradients.
 #include <stdlib.h>
 
 #include "gemm_tile.h"

@@ -37,6 +37,7 @@ for step in "$@"; do
     benchddp) BVC_FORCE_DDP=1 run benchddp 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --steps 20 --warmup 3 --no-cpu-baseline ;;
     benchov) BVC_DW_OVERLAP=1 run benchov 300 python bench.py --no-cpu-baseline ;;
     micro) run micro 400 python tools/microbench.py ;;
+    racescreen) run racescreen 500 python tools/persist_race_screen.py ;;
     gemmdbg) run gemmdbg 300 python tools/gemm_dbg.py ;;
     ksweep) run ksweep 400 python tools/gemm_ksweep.py ;;
     dwsweep) run dwsweep 400 python tools/dw_sweep.py ;;

@@ -68,7 +68,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
                                                      const float* __restrict__ gamma, float* __restrict__ dres,
                                                      int accumulate, bf16_t* __restrict__ dres_bf, float* __restrict__ part,
                                                      int M, int D) {
-    __shared__ float red[4][2][kMaxChunks * 256];
+    // per-wave column partials, [wave][dgamma | dbeta][D]: sized by D at launch (a static 32 KiB array capped the kernel at
+    // 5 workgroups per CU; at D = 384 this is 12 KiB and the register budget decides: 7)
+    extern __shared__ __attribute__((aligned(16))) float red[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nch = D >> 2;
     f32x4 gam[kMaxChunks], dg[kMaxChunks], db[kMaxChunks];
@@ -122,17 +124,17 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
     // cross-wave reduction of the column partials, then one atomic per column per workgroup
 #pragma unroll
     for (int i = 0; i < kMaxChunks; ++i) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            red[wave][0][(lane + 64 * i) * 4 + e] = dg[i][e];
-            red[wave][1][(lane + 64 * i) * 4 + e] = db[i][e];
+        const int c = lane + 64 * i;
+        if (c < nch) {
+            *reinterpret_cast<f32x4*>(red + (wave * 2 + 0) * D + c * 4) = dg[i];
+            *reinterpret_cast<f32x4*>(red + (wave * 2 + 1) * D + c * 4) = db[i];
         }
     }
     __syncthreads();
     float* pg = part + (size_t)blockIdx.x * 2 * D;
     for (int col = threadIdx.x; col < D; col += 256) {
-        pg[col] = (red[0][0][col] + red[1][0][col]) + (red[2][0][col] + red[3][0][col]);
-        pg[D + col] = (red[0][1][col] + red[1][1][col]) + (red[2][1][col] + red[3][1][col]);
+        pg[col] = (red[0 * D + col] + red[2 * D + col]) + (red[4 * D + col] + red[6 * D + col]);
+        pg[D + col] = (red[1 * D + col] + red[3 * D + col]) + (red[5 * D + col] + red[7 * D + col]);
     }
 }
 
@@ -733,12 +735,13 @@ int launch_ln_bwd(const bf16_t* dy, const float* x, RowMap rm, const float* mean
     // each wave walks its rows serially), few enough that the per-column atomics stay negligible
     const int rpb = ln_bwd_rows_per_block(M);
     const int nblk = (M + rpb - 1) / rpb;
+    const size_t lds = (size_t)8 * D * sizeof(float);
     if (rpb == 64)
-        hipLaunchKernelGGL(ln_bwd_kernel<64>, dim3(nblk), dim3(256), 0, s, dy, x, rm, mean, rstd, gamma, dres, accumulate, dres_bf, part, M, D);
+        hipLaunchKernelGGL(ln_bwd_kernel<64>, dim3(nblk), dim3(256), lds, s, dy, x, rm, mean, rstd, gamma, dres, accumulate, dres_bf, part, M, D);
     else if (rpb == 16)
-        hipLaunchKernelGGL(ln_bwd_kernel<16>, dim3(nblk), dim3(256), 0, s, dy, x, rm, mean, rstd, gamma, dres, accumulate, dres_bf, part, M, D);
+        hipLaunchKernelGGL(ln_bwd_kernel<16>, dim3(nblk), dim3(256), lds, s, dy, x, rm, mean, rstd, gamma, dres, accumulate, dres_bf, part, M, D);
     else
-        hipLaunchKernelGGL(ln_bwd_kernel<4>, dim3(nblk), dim3(256), 0, s, dy, x, rm, mean, rstd, gamma, dres, accumulate, dres_bf, part, M, D);
+        hipLaunchKernelGGL(ln_bwd_kernel<4>, dim3(nblk), dim3(256), lds, s, dy, x, rm, mean, rstd, gamma, dres, accumulate, dres_bf, part, M, D);
     hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * D + 255) / 256, (nblk + 15) / 16), dim3(256), 0, s, part, nblk, D, dgamma, dbeta);
     BVC_CHECK_HIP(hipGetLastError());
     return BVC_OK;

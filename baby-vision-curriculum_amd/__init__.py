@@ -9,7 +9,7 @@ Host-side mirror of the model interface the reference's entry points use
 ``libbvc_hip.so`` (hand-written HIP, C ABI in ``include/bvc.h``).  PyTorch is used for device
 memory, streams, the optimiser object and torch.distributed only.
 """
-from . import _lib  # noqa: F401
+from . import _lib, _ops  # noqa: F401
 from .videomae import (VideoMAEConfig, VideoMAEForPreTraining, VideoMAEForPreTrainingOutput, VideoMAEForVideoClassification,  # noqa: F401
                        get_config, get_model)
 from .mask import TubeMaskingGenerator, RandomMaskingGenerator  # noqa: F401

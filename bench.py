@@ -43,6 +43,36 @@ def measured_traffic(batch):
         return None, None
 
 
+def dominant_kernel_probe(bvc, batch, device):
+    """The step's dominant kernel, timed alone with HIP events on the launch stream: the decoder fc1 product of one layer
+    (M = batch x 1568 tokens, K = 384, N = 1536, bias + exact GELU epilogue writing `pre` and `act`; four such launches per
+    step, the persistent GEMM kernel at this size).  Algorithmic FLOPs 2MNK and algorithmic bytes (A + W read, two bf16
+    outputs written) per launch over the measured launch time."""
+    ops = bvc._ops
+    M, N, K = batch * 1568, 1536, 384
+    g = torch.Generator(device="cpu").manual_seed(0)
+    A = torch.randn(M, K, generator=g).to(device).to(torch.bfloat16)
+    W = (torch.randn(N, K, generator=g) * 0.02).to(device).to(torch.bfloat16)
+    bias = torch.zeros(N, device=device)
+    pre = torch.empty(M, N, device=device, dtype=torch.bfloat16)
+    act = torch.empty_like(pre)
+    d = ops.gemm_desc(A, W, M, N, K, ops.EPI["GELU"], pre, C2=act, bias=bias)
+    for _ in range(3):
+        ops.gemm(d, ops.NT)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    iters = 20
+    e0.record()
+    for _ in range(iters):
+        ops.gemm(d, ops.NT)
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / iters
+    flops, nbytes = 2.0 * M * N * K, 2.0 * (M * K + N * K + 2 * M * N)
+    return {"name": "gemm_persist_kernel<128, false> (decoder fc1 + GELU)", "shape": [M, N, K], "launch_us": round(us, 1),
+            "achieved_tflops": round(flops / us / 1e6, 1), "frac_mfma": round(flops / us / 1e6 / PEAK_BF16_TFLOPS, 4),
+            "algorithmic_gb_per_s": round(nbytes / us / 1e3, 1)}
+
+
 def synthetic_clips(batch, seed, device):
     """uint8 ~ U{0..255} frames through the loader's transform (x/255 - 0.5)/0.25 (homeview.py:218-231)."""
     g = torch.Generator().manual_seed(seed)
@@ -206,6 +236,8 @@ def main():
                          "kernel": "one training step = the fwd+bwd kernel sequence of libbvc_hip.so on the compute stream",
                          "flops_per_launch": GFLOP_PER_CLIP * 1e9 * B, "launch_ms": round(step_ms_gpu, 4)},
         }
+        if world == 1:
+            line["roofline"]["dominant_kernel"] = dominant_kernel_probe(bvc, B, dev)
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)

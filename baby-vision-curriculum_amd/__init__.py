@@ -16,5 +16,5 @@ from .mask import TubeMaskingGenerator, RandomMaskingGenerator  # noqa: F401
 from .ddp import DistributedDataParallel  # noqa: F401
 from .ddputils import AllReduce  # noqa: F401
 from .loggingtools import grad_logger  # noqa: F401
-from . import optim  # noqa: F401
+from . import optim, amp  # noqa: F401
 from . import simclr, distributed, jepa, jepa_mask, checkpoint  # noqa: F401

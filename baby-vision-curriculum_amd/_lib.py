@@ -137,6 +137,7 @@ SYMBOLS = {
     "bvc_op_adam_prepare": (c_int, [c_void_p, c_double, c_double, c_double, c_void_p, c_void_p]),
     "bvc_op_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_double, c_double, c_double, c_double, c_double,
                                  c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "bvc_op_nonfinite_check": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     "bvc_op_mask_index": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "bvc_op_gather_patches": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "bvc_op_pixel_labels": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),

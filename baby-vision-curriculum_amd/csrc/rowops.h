@@ -52,6 +52,7 @@ int launch_pad_heads(const bf16_t* wqkv, const float* bqkv, const bf16_t* wo, bf
                      int hd, int hdp, hipStream_t s);
 int launch_unpad_head_grads(const float* gwqkv_p, const float* gbqkv_p, const float* gwo_p, float* gwqkv, float* gbqkv, float* gwo, int D,
                             int H, int hd, int hdp, hipStream_t s);
+int launch_nonfinite_check(const float* x, size_t n, float* found_inf, hipStream_t s);
 int launch_row_normalize(const float* f, bf16_t* fn, float* inv, int n, int p, float eps, hipStream_t s);
 int launch_row_normalize_bwd(const float* f, const float* inv, const float* dfn, float* df, int n, int p, hipStream_t s);
 int launch_nce_finalize(const float* partial, int ntiles, float inv_t, double npos, float* loss, float* stats, hipStream_t s);

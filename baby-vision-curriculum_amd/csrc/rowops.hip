@@ -697,6 +697,23 @@ __global__ void unpad_cols_grad_kernel(const float* __restrict__ gwp, float* __r
     }
 }
 
+// GradScaler's inf check as ONE read-only pass: *found_inf = 1 if any element of x is Inf or NaN (never cleared here).
+// torch does it with _amp_foreach_non_finite_check_and_unscale_(grads, found_inf, inv_scale = 1): a read AND a write of every
+// gradient, 6 multi-tensor launches for VideoMAE-base (0.24 ms per step at 3.1 TB/s); this reads 377 MB once.
+__global__ void nonfinite_check_kernel(const float* __restrict__ x, size_t n, float* __restrict__ found_inf) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x * 4;
+    bool bad = false;
+    size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    for (; i + 4 <= n; i += stride) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + i);
+        // (v - v) is 0 for finite values and NaN for Inf / NaN
+        const float t = (v[0] - v[0]) + (v[1] - v[1]) + (v[2] - v[2]) + (v[3] - v[3]);
+        bad |= (t != 0.f);
+    }
+    for (; i < n; ++i) bad |= ((x[i] - x[i]) != 0.f);      // tail of the last vector
+    if (__any(bad) && (threadIdx.x & 63) == 0) *found_inf = 1.0f;
+}
+
 // ============================================================================ launchers
 static inline unsigned blocks_for(size_t items, int per = 256) { return (unsigned)((items + per - 1) / per); }
 
@@ -939,6 +956,16 @@ int launch_unpad_head_grads(const float* gwqkv_p, const float* gbqkv_p, const fl
                             int H, int hd, int hdp, hipStream_t s) {
     hipLaunchKernelGGL(unpad_qkv_grad_kernel, dim3(3 * H * hd), dim3(128), 0, s, gwqkv_p, gbqkv_p, gwqkv, gbqkv, H, hd, hdp, D);
     hipLaunchKernelGGL(unpad_cols_grad_kernel, dim3(D), dim3(128), 0, s, gwo_p, gwo, D, H, hd, hdp);
+    BVC_CHECK_HIP(hipGetLastError());
+    return BVC_OK;
+}
+
+int launch_nonfinite_check(const float* x, size_t n, float* found_inf, hipStream_t s) {
+    BVC_REQUIRE(((uintptr_t)x % 16) == 0, "nonfinite_check: buffer must be 16-byte aligned");
+    if (n == 0) return BVC_OK;
+    const size_t want = (n / 4 + 255) / 256 + 1;
+    const unsigned blocks = (unsigned)(want < 8192 ? want : 8192);
+    hipLaunchKernelGGL(nonfinite_check_kernel, dim3(blocks), dim3(256), 0, s, x, n, found_inf);
     BVC_CHECK_HIP(hipGetLastError());
     return BVC_OK;
 }

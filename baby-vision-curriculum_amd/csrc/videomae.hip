@@ -554,6 +554,10 @@ int bvc_op_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg
     return launch_adam_step(params, grads, exp_avg, exp_avg_sq, (size_t)n, lr, beta1, beta2, eps, weight_decay, decoupled, maximize,
                             state3, grad_scale, found_inf, write_unscaled_grads, (hipStream_t)stream);
 }
+int bvc_op_nonfinite_check(const float* x, int64_t n, float* found_inf, void* stream) {
+    BVC_REQUIRE(x && found_inf && n >= 0, "op_nonfinite_check: bad argument");
+    return launch_nonfinite_check(x, (size_t)n, found_inf, (hipStream_t)stream);
+}
 int bvc_op_row_normalize(const float* f, void* fn_bf16, float* inv_norm, int n, int p, float eps, void* stream) {
     BVC_REQUIRE(f && fn_bf16 && inv_norm, "op_row_normalize: null argument");
     return launch_row_normalize(f, (bf16_t*)fn_bf16, inv_norm, n, p, eps, (hipStream_t)stream);

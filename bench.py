@@ -164,7 +164,9 @@ def main():
     # HIP launch over the flat parameter buffer (--torch-sgd switches back to torch.optim.SGD)
     SGD = torch.optim.SGD if args.torch_sgd else bvc.optim.SGD
     opt = SGD(xmodel.parameters(), lr=0.1, momentum=0.9, nesterov=True, weight_decay=0.0)
-    scaler = torch.amp.GradScaler("cuda")
+    # the reference's GradScaler object (pretrain_videomae.py:197); bvc.amp.GradScaler is the same class with its inf check
+    # done as one read-only pass over the flat gradient buffer (--torch-sgd also switches back to the stock scaler)
+    scaler = torch.amp.GradScaler("cuda") if args.torch_sgd else bvc.amp.GradScaler("cuda")
     B = args.batch
     clips = synthetic_clips(B, 1234 + rank, dev)
     mask_gen = bvc.TubeMaskingGenerator((8, 14, 14), 0.9, rng=np.random.RandomState(1234 + rank))

@@ -254,6 +254,9 @@ int bvc_op_adam_prepare(float* state3, double lr, double beta1, double beta2, co
 int bvc_op_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, double lr, double beta1, double beta2,
                      double eps, double weight_decay, int decoupled, int maximize, const float* state3, const float* grad_scale,
                      const float* found_inf, int write_unscaled_grads, void* stream);
+/* GradScaler's inf check (scaler.step at pretrain_videomae.py:313 -> torch.amp.GradScaler._check_inf_per_device) as one read-only
+ * pass over a flat f32 range: *found_inf (device f32) is set to 1 if any element is Inf or NaN; it is never cleared here. */
+int bvc_op_nonfinite_check(const float* x, int64_t n, float* found_inf, void* stream);
 /* boolean mask -> ascending visible / masked token lists (the order x[~mask] / x[mask] produce, HF:121,578-579) */
 int bvc_op_mask_index(const uint8_t* mask, int B, int L, int nvis, int nmask, int* vis_idx, int* msk_idx, int* status, void* stream);
 /* tube patches of the visible tokens in Conv3d weight order (HF:157-177) */

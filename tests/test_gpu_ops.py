@@ -566,3 +566,51 @@ def test_gemm_persistent_is_the_default_for_eligible_products():
         outs.append(C)
     assert torch.equal(outs[0], outs[1])
     assert G.rel_err(outs[0].float(), _ref_gemm(A, B, G.NT)) < 4e-3
+
+
+# --------------------------------------------------------------------------- fused inf check / bvc.amp.GradScaler
+@pytest.mark.parametrize("n", [1, 3, 4, 1023, 1 << 20, (1 << 22) + 5])
+def test_nonfinite_check_kernel(n):
+    x = (torch.randn(n + 4, device=dev) * 1e30)[:n] if n > 4 else torch.randn(8, device=dev)[:n]
+    x = x.contiguous()
+    if x.data_ptr() % 16:
+        x = x.clone()
+    x[0] = 3.0e38                                 # large but finite: no false positive
+    flag = torch.zeros((), device=dev)
+    L.check(L.lib().bvc_op_nonfinite_check(G.ptr(x), n, G.ptr(flag), G.stream()), "nonfinite")
+    assert float(flag) == 0.0
+    for pos, val in ((n - 1, float("inf")), (n // 2, float("nan")), (0, float("-inf"))):
+        y = x.clone()
+        y[pos] = val
+        flag.zero_()
+        L.check(L.lib().bvc_op_nonfinite_check(G.ptr(y), n, G.ptr(flag), G.stream()), "nonfinite")
+        assert float(flag) == 1.0, (n, pos, val)
+
+
+def test_bvc_gradscaler_matches_torch_gradscaler():
+    """bvc.amp.GradScaler (one read-only inf-check pass) against torch.amp.GradScaler on the same sequence of good and poisoned
+    steps: same parameters, same scale trajectory, same skipped steps."""
+    torch.manual_seed(0)
+    n = 10007
+    outs = []
+    for cls in (torch.amp.GradScaler, G.bvc.amp.GradScaler):
+        flat, gflat = torch.linspace(-1, 1, n, device=dev).clone(), torch.zeros(n, device=dev)
+        p = torch.nn.Parameter(flat)
+        opt = G.bvc.optim.SGD([p], lr=0.1, momentum=0.9, nesterov=True)
+        scaler = cls("cuda", init_scale=256.0, growth_interval=2)
+        scaler.scale(torch.zeros((), device=dev))
+        scales = []
+        gen = torch.Generator(device="cpu").manual_seed(1)
+        for poison in (False, True, False, False, True, False):
+            g = torch.randn(n, generator=gen).to(dev) * scaler.get_scale()
+            if poison:
+                g[n - 1] = float("nan")
+            p.grad = gflat
+            gflat.copy_(g)
+            scaler.step(opt)
+            scaler.update()
+            scales.append(scaler.get_scale())
+        torch.cuda.synchronize()
+        outs.append((flat.clone(), scales))
+    assert outs[0][1] == outs[1][1]
+    assert torch.equal(outs[0][0], outs[1][0])

@@ -64,9 +64,10 @@ for step in "$@"; do
            run pmc_attn2 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS --output-format csv -d $OUT/pmc/b -- python3 $R/tools/attn_only.py
            cd $R ;;
     pmc_gemm) rm -rf $OUT/pmcg; cd /tmp
-           run pmc_gemm1 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS --output-format csv -d $OUT/pmcg/a -- python3 $R/tools/gemm_only.py
-           run pmc_gemm2 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SALU SQ_LDS_UNALIGNED_STALL --output-format csv -d $OUT/pmcg/b -- python3 $R/tools/gemm_only.py
-           cd $R ;;
+           run pmc_gemm1 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA --output-format csv -d $OUT/pmcg/a -- python3 $R/tools/gemm_only.py
+           run pmc_gemm2 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_SALU SQ_INST_CYCLES_VMEM --output-format csv -d $OUT/pmcg/b -- python3 $R/tools/gemm_only.py
+           cd $R
+           run pmc_gemm_summary 60 python tools/pmc_summary.py $OUT/pmcg/a $OUT/pmcg/b $OUT/pmc_gemm_summary.txt ;;
     *) echo "unknown step $step" ;;
   esac
 done

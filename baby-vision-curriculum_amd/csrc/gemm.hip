@@ -540,7 +540,7 @@ int launch_gemm_persist(const GemmGroup& g, GemmLayout layout, int cfg, hipStrea
 
 int launch_gemm(const GemmProblem* probs, int nprob, GemmLayout layout, int tile_cfg, hipStream_t stream, int stages) {
     BVC_REQUIRE(nprob >= 1 && nprob <= kMaxGroup, "launch_gemm: nprob %d out of range", nprob);
-    if (tile_cfg >= 3 && tile_cfg <= 5) {
+    if ((tile_cfg >= 3 && tile_cfg <= 5) || tile_cfg == 8) {
         BVC_REQUIRE(nprob == 1 && layout == GEMM_NT, "launch_gemm: tile configs 3-5 (32-deep K steps) are NT, one problem");
         return launch_gemm_big_nt(probs[0], tile_cfg, stream);
     }

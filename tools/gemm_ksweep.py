@@ -43,15 +43,15 @@ def run(M, N, K, layout, epi, tile):
 Bc = int(os.environ.get("BVC_BATCH", "64"))
 M = Bc * 1568
 for N, layout, epi in ((1152, G.NT, "BF16"), (1536, G.NT, "GELU"), (1536, G.NN, "DGELU"), (384, G.NT, "BF16")):
-    for tile in ((0, 1, 2, 3, 4, 5) if (layout == G.NT and epi == "BF16") else (0,)):
+    for tile in ((0, 6, 3, 8) if (layout == G.NT and epi == "BF16") else (0, 6)):
         row = []
-        for K in (64, 128, 256, 384, 768, 1536):
+        for K in ((128, 256, 384, 768, 1536) if tile == 6 else (64, 128, 256, 384, 768, 1536)):
             ms = run(M, N, K, layout, epi, tile)
             row.append((K, ms))
         (k0, t0), (k1, t1) = row[0], row[-1]
         slope = (t1 - t0) / (k1 - k0)
         icpt = t0 - slope * k0
-        tiles = -(-M // (256 if tile == 3 else 64 if tile == 2 else 128)) * -(-N // (64 if tile in (1, 2) else 128))
+        tiles = -(-M // (256 if tile in (3, 8) else 64 if tile == 2 else 128)) * -(-N // (64 if tile in (1, 2) else 128))
         emit(f"M={M} N={N} {['NT','NN','TN'][layout]} {epi:5s} tile{tile}: " + " ".join(f"K{k}={ms*1e3:.0f}us" for k, ms in row) +
              f" | intercept {icpt*1e3:.0f}us slope {2.0*M*N/slope/1e9:.0f}TF marginal | {tiles} tiles")
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)

@@ -446,6 +446,7 @@ static int tiles_for(const GemmProblem& p, int cfg) {
 
 int gemm_pick_tile(const GemmProblem* probs, int nprob, int tile_cfg) {
     if (tile_cfg == 6 || tile_cfg == 7) return tile_cfg - 6;     // the persistent kernel: 128x128 / 128x64 tiles
+    if (tile_cfg == 9) return 0;                                  // persistent 128x128 with deferred stores
     if (tile_cfg >= 0) return tile_cfg;
     // Measured on MI355X (profiles/r01_b_microbench.json): a workgroup's speed is set by its L2->LDS fill
     // rate (~70 GB/s per CU), so the big tile (64 FLOP/B) wins once it alone covers the 256 CUs ~1.5x;
@@ -536,7 +537,9 @@ static int launch_stages(const GemmGroup& g, GemmLayout layout, int stages, int 
 int gemm_pick_stages(int, GemmLayout, int, int stages) { return (stages == 3 || stages == 4) ? stages : 2; }
 
 int launch_gemm_big_nt(const GemmProblem& p, int cfg, hipStream_t stream);   // gemm_big.hip (experiments: tile configs 3-5)
-int launch_gemm_persist(const GemmGroup& g, GemmLayout layout, int cfg, hipStream_t stream);   // gemm_persist.hip; 1 = not eligible
+// gemm_persist.hip; returns 1 when the problem is not eligible.  defer: 0 = stores in the epilogue, 1 = deferred where possible,
+// 2 = deferred or not at all (tile config 9, tests)
+int launch_gemm_persist(const GemmGroup& g, GemmLayout layout, int cfg, hipStream_t stream, int defer);
 
 int launch_gemm(const GemmProblem* probs, int nprob, GemmLayout layout, int tile_cfg, hipStream_t stream, int stages) {
     BVC_REQUIRE(nprob >= 1 && nprob <= kMaxGroup, "launch_gemm: nprob %d out of range", nprob);
@@ -581,10 +584,15 @@ int launch_gemm(const GemmProblem* probs, int nprob, GemmLayout layout, int tile
     // third resident workgroup per CU matters more than the chaining - so it is taken up to K = 512 only.
     const bool auto_persist = tile_cfg < 0 && stages < 3 && g.dbg == 0 && (cfg == 0 || (cfg == 1 && probs[0].K <= 512)) &&
                               getenv("BVC_GEMM_NO_PERSIST") == nullptr;
-    if (nprob == 1 && (tile_cfg >= 6 || auto_persist)) {
-        const int rc = launch_gemm_persist(g, layout, cfg, stream);
+    if (nprob == 1 && (tile_cfg == 6 || tile_cfg == 7 || tile_cfg == 9 || auto_persist)) {
+        // deferred stores (gemm_persist.hip) measured on the decoder shapes at B=64 (profiles/r01_f_gemm_ksweep_b64.txt, tile 9 vs 6):
+        // GELU' epilogue -8 ... -18 % at K <= 384, -2 % at K = 768; plain bf16 +-0; GELU (two outputs, 253 VGPRs) +8 % slower.
+        // So: the GELU' products only.  BVC_GEMM_DEFER=1 / =0 force it on (where possible) / off for A/Bs.
+        const char* dv = getenv("BVC_GEMM_DEFER");
+        const int defer = tile_cfg == 9 ? 2 : tile_cfg >= 0 ? 0 : dv ? (dv[0] == '1' ? 1 : 0) : (probs[0].epi == EPI_DGELU ? 1 : 0);
+        const int rc = launch_gemm_persist(g, layout, cfg, stream, defer);
         if (rc != 1) return rc;
-        BVC_REQUIRE(tile_cfg < 6, "launch_gemm: tile configs 6 / 7 (persistent 128x128 / 128x64) do not take this problem");
+        BVC_REQUIRE(tile_cfg < 6, "launch_gemm: tile configs 6 / 7 / 9 (persistent kernels) do not take this problem");
     }
     switch (cfg) {
         case 0: return launch_stages<128, 128>(g, layout, ns, total, stream);

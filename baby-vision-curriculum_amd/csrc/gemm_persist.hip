@@ -37,7 +37,31 @@ __device__ __forceinline__ void tile_of(int t, int tiles_m, int tiles_n, int G, 
 
 }  // namespace
 
-template <int BN, bool BT>
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt_n() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// counted wait with a run-time count out of the few values the deferred-store schedule produces (multiples of 4 up to 24)
+__device__ __forceinline__ void wait_vmcnt_dyn(int n) {
+    switch (n) {
+        case 0: wait_vmcnt_n<0>(); break;
+        case 4: wait_vmcnt_n<4>(); break;
+        case 8: wait_vmcnt_n<8>(); break;
+        case 12: wait_vmcnt_n<12>(); break;
+        case 16: wait_vmcnt_n<16>(); break;
+        case 20: wait_vmcnt_n<20>(); break;
+        default: wait_vmcnt_n<24>(); break;
+    }
+}
+
+// DEFER (128x128 tiles, bf16-output epilogues): the finished tile is NOT stored by its epilogue; its packed bf16 chunks stay
+// in registers and are stored during the first two K steps of the NEXT tile, after that step's refill loads.  vmcnt is one
+// in-order counter, so a store issued before a load delays every wait for that load; issued after it, and with the EXACT
+// number of younger operations written into the counted wait, the stores drain in the background for two K steps before
+// any wait reaches them.  The count is exact because every chunk is stored through a buffer descriptor (rows / columns past
+// the matrix get an out-of-range offset: dropped by the hardware, still counted).
+// DEFER: 0 = stores in the epilogue; 1 = one bf16 output held (BF16, DGELU); 2 = two (GELU: pre and act)
+template <int BN, bool BT, int DEFER = 0>
 __global__ __launch_bounds__(256, 2) void gemm_persist_kernel(const GemmGroup g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int BM = 128, BK = 64;
@@ -71,6 +95,16 @@ __global__ __launch_bounds__(256, 2) void gemm_persist_kernel(const GemmGroup g)
     AS3 char* wl = (AS3 char*)smem + 2 * STAGE + wave * (16 * WN * 4);     // wave-private epilogue parking: 16 rows x WN f32
     const int epi = p.epi;
     const float alpha = p.alpha_dev ? p.alpha * p.alpha_dev[0] : p.alpha;
+    // deferred stores (DEFER): packed chunks of the previous tile and where they go
+    constexpr int NST = 4;                               // chunks stored per K step and per output tensor
+    constexpr bool two_out = DEFER == 2;
+    constexpr int nst = DEFER * NST;
+    const uint32_t c_bytes = (uint32_t)((size_t)p.M * p.ldc * 2);
+    const __amdgpu_buffer_rsrc_t rc0 = make_rsrc(p.C, c_bytes);
+    const __amdgpu_buffer_rsrc_t rc1 = make_rsrc(two_out ? p.C2 : p.C, c_bytes);
+    u32x4 held0[DEFER ? NSIDE : 1], held1[DEFER == 2 ? NSIDE : 1];
+    bool pending = false;
+    int m0p = 0, n0p = 0;
 
     int tm, tn;
     tile_of(lid, tiles_m, tiles_n, G, tm, tn);
@@ -129,15 +163,37 @@ __global__ __launch_bounds__(256, 2) void gemm_persist_kernel(const GemmGroup g)
                 stage_tile<BM, false>(ra, mm, kk, p.lda, slot, wave, lane);
                 stage_tile<BN, BT>(rb, nn, kk, p.ldb, slot + A_BYTES, wave, lane);
             }
+            if (DEFER && pending && it < 2) {
+                // half of the previous tile's chunks, AFTER this step's refill loads (see the kernel comment)
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int q = 0; q < NST; ++q) {
+                    const int c = it * NST + q;                  // NSIDE == 2 * NST
+                    const int m = m0p + wm * WM + 16 * (c / U) + (((c % U) * 64 + lane) / CPR);
+                    const int n = n0p + wn * WN + (lane % CPR) * 8;
+                    const uint32_t off = (m < p.M && n < p.N) ? (uint32_t)(((size_t)m * p.ldc + n) * 2) : 0xFFFFFFF0u;
+                    __builtin_amdgcn_raw_buffer_store_b128(it == 0 ? held0[q] : held0[NST + q], rc0, off, 0, 0);
+                    if constexpr (two_out) __builtin_amdgcn_raw_buffer_store_b128(it == 0 ? held1[q] : held1[NST + q], rc1, off, 0, 0);
+                }
+                asm volatile("" ::: "memory");
+            }
             mfma_half(1);
             if (it + 1 < nt || has_next) {     // the stream continues: K step + 1 must have landed everywhere
                 if (!fresh) {
-                    if (refill) wait_vmcnt<DMA_PER_STAGE>(); else wait_vmcnt<0>();
+                    if (DEFER) {
+                        // operations younger than the loads of K step + 1: this step's refill, and the deferred stores issued
+                        // after those loads (both halves at it == 1, the second half at it == 2)
+                        const int stores = pending ? (it == 1 ? 2 * nst : it == 2 ? nst : 0) : 0;
+                        wait_vmcnt_dyn((refill ? DMA_PER_STAGE : 0) + stores);
+                    } else {
+                        if (refill) wait_vmcnt<DMA_PER_STAGE>(); else wait_vmcnt<0>();
+                    }
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             }
             fresh = false;
         }
+        pending = false;
 
         // ------------------------------------------------------------------ epilogue of this tile
         // lane -> (row, 8-column chunk) of each 16-row round: pass u covers rows (64 u + lane) / CPR, columns 8 (lane % CPR) ..
@@ -149,21 +205,23 @@ __global__ __launch_bounds__(256, 2) void gemm_persist_kernel(const GemmGroup g)
             bias0 = *reinterpret_cast<const f32x4*>(p.bias + n);
             bias1 = *reinterpret_cast<const f32x4*>(p.bias + n + 4);
         }
-        f32x4 side0[NSIDE], side1[NSIDE];
-        const bool side_f32 = epi == EPI_RESID, side_aux = epi == EPI_DGELU;
+        f32x4 side0[NSIDE], side1[DEFER ? 1 : NSIDE];       // the f32 addend (residual) exists only where stores are not deferred
+        const bool side_f32 = DEFER == 0 && epi == EPI_RESID, side_aux = DEFER != 2 && epi == EPI_DGELU;
         if (side_f32 || side_aux) {
 #pragma unroll
             for (int c = 0; c < NSIDE; ++c) {
                 const int m = m0 + wm * WM + 16 * (c / U) + (((c % U) * 64 + lane) / CPR);
                 side0[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-                side1[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if constexpr (DEFER == 0) side1[c] = f32x4{0.f, 0.f, 0.f, 0.f};
                 if (m >= p.M || !ncol_ok) continue;
                 if (side_aux) {
                     side0[c] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const bf16_t*>(p.aux) + (size_t)m * p.ldaux + n);
                 } else {
-                    const float* src = p.resid + (size_t)m * p.ldc + n;
-                    side0[c] = *reinterpret_cast<const f32x4*>(src);
-                    side1[c] = *reinterpret_cast<const f32x4*>(src + 4);
+                    if constexpr (DEFER == 0) {
+                        const float* src = p.resid + (size_t)m * p.ldc + n;
+                        side0[c] = *reinterpret_cast<const f32x4*>(src);
+                        side1[c] = *reinterpret_cast<const f32x4*>(src + 4);
+                    }
                 }
             }
         }
@@ -195,24 +253,32 @@ __global__ __launch_bounds__(256, 2) void gemm_persist_kernel(const GemmGroup g)
                     *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
                     *reinterpret_cast<f32x4*>(dst + 4) = f32x4{v[4], v[5], v[6], v[7]};
                 };
-                auto store_bf16 = [&](void* base, const float* w) {
-                    *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(base) + idx) =
-                        uint4{pack2bf(w[0], w[1]), pack2bf(w[2], w[3]), pack2bf(w[4], w[5]), pack2bf(w[6], w[7])};
+                const bool hold = DEFER && has_next;       // uniform: the chunk waits in registers for the next tile's first K steps
+                auto store_bf16 = [&](void* base, const float* w, bool second) {
+                    const u32x4 pk = {pack2bf(w[0], w[1]), pack2bf(w[2], w[3]), pack2bf(w[4], w[5]), pack2bf(w[6], w[7])};
+                    if (hold) {
+                        if constexpr (DEFER == 2) { if (second) held1[c] = pk; else held0[c] = pk; }
+                        else if constexpr (DEFER == 1) held0[c] = pk;
+                    } else {
+                        *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(base) + idx) = pk;
+                    }
                 };
                 switch (epi) {
                     case EPI_F32: store_f32(reinterpret_cast<float*>(p.C) + idx); break;
-                    case EPI_BF16: store_bf16(p.C, v); break;
+                    case EPI_BF16: store_bf16(p.C, v, false); break;
                     case EPI_GELU: {
-                        store_bf16(p.C, v);
+                        store_bf16(p.C, v, false);
                         float a[8];
 #pragma unroll
                         for (int e = 0; e < 8; ++e) a[e] = gelu_f(v[e]);
-                        store_bf16(p.C2, a);
+                        store_bf16(p.C2, a, true);
                     } break;
                     case EPI_RESID: {
+                        if constexpr (DEFER == 0) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) { v[e] += side0[c][e]; v[4 + e] += side1[c][e]; }
-                        store_f32(reinterpret_cast<float*>(p.C) + idx);
+                            for (int e = 0; e < 4; ++e) { v[e] += side0[c][e]; v[4 + e] += side1[c][e]; }
+                            store_f32(reinterpret_cast<float*>(p.C) + idx);
+                        }
                     } break;
                     case EPI_DGELU: {
 #pragma unroll
@@ -221,11 +287,12 @@ __global__ __launch_bounds__(256, 2) void gemm_persist_kernel(const GemmGroup g)
                             v[2 * e] *= dgelu_f(__uint_as_float(w << 16));
                             v[2 * e + 1] *= dgelu_f(__uint_as_float(w & 0xffff0000u));
                         }
-                        store_bf16(p.C, v);
+                        store_bf16(p.C, v, false);
                     } break;
                     case EPI_F32_BF16: {
                         store_f32(reinterpret_cast<float*>(p.C) + idx);
-                        store_bf16(p.C2, v);
+                        *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.C2) + idx) =
+                            u32x4{pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
                     } break;
                     default: break;
                 }
@@ -235,27 +302,28 @@ __global__ __launch_bounds__(256, 2) void gemm_persist_kernel(const GemmGroup g)
         // every wave drained its own share of the next tile's stages before its stores; the barrier makes that true of all four
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         fresh = true;
+        if (DEFER) { pending = true; m0p = m0; n0p = n0; }
         lid = lid_next; m0 = m0n; n0 = n0n;
     }
 }
 
 // Launcher hook used by launch_gemm (gemm.hip).  cfg 0 = 128x128 tiles, 1 = 128x64.  Returns BVC_OK after launching, or 1 when
 // the problem is not eligible.
-template <int BN, bool BT>
+template <int BN, bool BT, int DEFER = 0>
 static int launch_persist_one(const GemmGroup& g, hipStream_t stream) {
     constexpr size_t lds = 2 * (size_t)(128 + BN) * 64 * 2 + 4 * 16 * (BN / 2) * 4;     // stages + parking: 80 KiB / 56 KiB
     static bool attr_set = false;
     if (lds > 65536 && !attr_set) {
-        BVC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_persist_kernel<BN, BT>),
+        BVC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_persist_kernel<BN, BT, DEFER>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_persist_kernel<BN, BT>), dim3(512), dim3(256), lds, stream, g);    // 256 CUs x 2 resident workgroups
+    hipLaunchKernelGGL((gemm_persist_kernel<BN, BT, DEFER>), dim3(512), dim3(256), lds, stream, g);    // 256 CUs x 2 resident workgroups
     BVC_CHECK_HIP(hipGetLastError());
     return BVC_OK;
 }
 
-int launch_gemm_persist(const GemmGroup& g, GemmLayout layout, int cfg, hipStream_t stream) {
+int launch_gemm_persist(const GemmGroup& g, GemmLayout layout, int cfg, hipStream_t stream, int defer) {
     const GemmProblem& p = g.prob[0];
     const int bn = cfg == 0 ? 128 : 64;
     const int tiles = ((p.M + 127) / 128) * ((p.N + bn - 1) / bn);
@@ -264,6 +332,14 @@ int launch_gemm_persist(const GemmGroup& g, GemmLayout layout, int cfg, hipStrea
     if (!(layout == GEMM_NT || layout == GEMM_NN) || cfg > 1 || p.split_k != 1 || !epi_ok || p.K % 64 != 0 || p.K < 128 || g.panel[0] <= 0)
         return 1;
     if (tiles < 2 * 512) return 1;               // fewer than two rounds of the resident workgroups: nothing to chain
+    // deferred stores: 128x128 tiles, epilogues whose outputs are bf16, output below 4 GiB (buffer-descriptor stores)
+    const bool defer_ok = cfg == 0 && (epi == EPI_BF16 || epi == EPI_GELU || epi == EPI_DGELU) && (size_t)p.M * p.ldc * 2 < 0xFFFFFFF0ull;
+    if (defer == 2 && !defer_ok) return 1;
+    if (defer && defer_ok) {
+        if (epi == EPI_GELU)
+            return layout == GEMM_NT ? launch_persist_one<128, false, 2>(g, stream) : launch_persist_one<128, true, 2>(g, stream);
+        return layout == GEMM_NT ? launch_persist_one<128, false, 1>(g, stream) : launch_persist_one<128, true, 1>(g, stream);
+    }
     if (cfg == 0) return layout == GEMM_NT ? launch_persist_one<128, false>(g, stream) : launch_persist_one<128, true>(g, stream);
     return layout == GEMM_NT ? launch_persist_one<64, false>(g, stream) : launch_persist_one<64, true>(g, stream);
 }

@@ -43,9 +43,9 @@ def run(M, N, K, layout, epi, tile):
 Bc = int(os.environ.get("BVC_BATCH", "64"))
 M = Bc * 1568
 for N, layout, epi in ((1152, G.NT, "BF16"), (1536, G.NT, "GELU"), (1536, G.NN, "DGELU"), (384, G.NT, "BF16")):
-    for tile in ((0, 6, 3, 8) if (layout == G.NT and epi == "BF16") else (0, 6)):
+    for tile in ((0, 6, 9) if N != 384 else (0, 6, 9)):
         row = []
-        for K in ((128, 256, 384, 768, 1536) if tile == 6 else (64, 128, 256, 384, 768, 1536)):
+        for K in ((128, 256, 384, 768, 1536) if tile in (6, 9) else (64, 128, 256, 384, 768, 1536)):
             ms = run(M, N, K, layout, epi, tile)
             row.append((K, ms))
         (k0, t0), (k1, t1) = row[0], row[-1]

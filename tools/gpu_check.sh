@@ -58,6 +58,14 @@ for step in "$@"; do
            cd $R
            run traffic 60 python tools/pmc_traffic.py $OUT/pmct/rd $OUT/pmct/wr 3 ${BVC_BATCH:-16} $OUT/traffic_b${BVC_BATCH:-16}.json
            find $OUT/pmct -name "*.csv" -size +5M -delete ;;
+    prof_jepa) rm -rf $OUT/prof_jepa; cd /tmp
+           run prof_jepa 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_jepa -- python3 $R/tools/bench_jepa.py --model vit_large --steps 5 --warmup 2
+           cd $R; find $OUT/prof_jepa -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/kernel_stats_jepa_vitl.csv
+           find $OUT/prof_jepa -name "*kernel_trace.csv" -delete ;;
+    prof_simclr) rm -rf $OUT/prof_simclr; cd /tmp
+           run prof_simclr 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_simclr -- python3 $R/tools/bench_simclr.py --vit
+           cd $R; find $OUT/prof_simclr -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/kernel_stats_simclr_vitb.csv
+           find $OUT/prof_simclr -name "*kernel_trace.csv" -delete ;;
     table) run table 60 python tools/roofline_table.py $OUT/kernel_stats.csv $OUT/traffic_b${BVC_BATCH:-16}.json 7 $OUT/roofline_table_b${BVC_BATCH:-16}.txt ;;
     pmc_attn) rm -rf $OUT/pmc; cd /tmp
            run pmc_attn1 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d $OUT/pmc/a -- python3 $R/tools/attn_only.py

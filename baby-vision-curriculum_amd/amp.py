@@ -14,12 +14,16 @@ from .optim import SGD
 
 class GradScaler(torch.amp.GradScaler):
     def _check_inf_per_device(self, optimizer):
-        _scale, _ = self._check_scale_growth_tracker("_check_inf_per_device")
+        # This overrides a private hook of torch.amp.GradScaler (torch 2.10: called from step() for optimisers that consume the
+        # scale themselves).  Anything unexpected - a torch release that renamed the internals, gradients that are not
+        # contiguous f32 CUDA ranges - falls back to the stock implementation.
         try:
+            _scale, _ = self._check_scale_growth_tracker("_check_inf_per_device")
+            states = self._per_optimizer_states
             runs = []
             for group in optimizer.param_groups:
                 runs += SGD._contiguous_runs(group["params"])
-        except _lib.BvcError:
+        except (_lib.BvcError, AttributeError, TypeError):
             return super()._check_inf_per_device(optimizer)
         per_device = {}
         L = _lib.lib()
@@ -33,5 +37,5 @@ class GradScaler(torch.amp.GradScaler):
                                                     _lib.current_stream_ptr()), "bvc_op_nonfinite_check")
         if not per_device:
             per_device[_scale.device] = torch.zeros((), dtype=torch.float32, device=_scale.device)
-        self._per_optimizer_states[id(optimizer)]["found_inf_per_device"] = per_device
+        states[id(optimizer)]["found_inf_per_device"] = per_device
         return per_device

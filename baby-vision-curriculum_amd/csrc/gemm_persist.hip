@@ -331,7 +331,8 @@ int launch_gemm_persist(const GemmGroup& g, GemmLayout layout, int cfg, hipStrea
     const bool epi_ok = epi == EPI_F32 || epi == EPI_BF16 || epi == EPI_GELU || epi == EPI_RESID || epi == EPI_DGELU || epi == EPI_F32_BF16;
     if (!(layout == GEMM_NT || layout == GEMM_NN) || cfg > 1 || p.split_k != 1 || !epi_ok || p.K % 64 != 0 || p.K < 128 || g.panel[0] <= 0)
         return 1;
-    if (tiles < 2 * 512) return 1;               // fewer than two rounds of the resident workgroups: nothing to chain
+    static const int min_tiles = getenv("BVC_PERSIST_MIN_TILES") ? atoi(getenv("BVC_PERSIST_MIN_TILES")) : 2 * 512;
+    if (tiles < min_tiles) return 1;             // fewer than two rounds of the resident workgroups: little to chain
     // deferred stores: 128x128 tiles, epilogues whose outputs are bf16, output below 4 GiB (buffer-descriptor stores)
     const bool defer_ok = cfg == 0 && (epi == EPI_BF16 || epi == EPI_GELU || epi == EPI_DGELU) && (size_t)p.M * p.ldc * 2 < 0xFFFFFFF0ull;
     if (defer == 2 && !defer_ok) return 1;

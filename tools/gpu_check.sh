@@ -58,6 +58,10 @@ for step in "$@"; do
            cd $R
            run traffic 60 python tools/pmc_traffic.py $OUT/pmct/rd $OUT/pmct/wr 3 ${BVC_BATCH:-16} $OUT/traffic_b${BVC_BATCH:-16}.json
            find $OUT/pmct -name "*.csv" -size +5M -delete ;;
+    profdefault) rm -rf $OUT/profd; cd /tmp
+           run profdefault 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/profd -- python3 $R/bench.py
+           cd $R; find $OUT/profd -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/kernel_stats_default.csv
+           find $OUT/profd -name "*kernel_trace.csv" -delete ;;
     prof_jepa) rm -rf $OUT/prof_jepa; cd /tmp
            run prof_jepa 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_jepa -- python3 $R/tools/bench_jepa.py --model vit_large --steps 5 --warmup 2
            cd $R; find $OUT/prof_jepa -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/kernel_stats_jepa_vitl.csv

@@ -576,7 +576,13 @@ int launch_gemm(const GemmProblem* probs, int nprob, GemmLayout layout, int tile
     for (int i = nprob; i < kMaxGroup; ++i) { g.prob[i] = probs[0]; g.panel[i] = g.panel[0]; g.tile_start[i + 1] = total; }
     int kmax = 0;
     for (int i = 0; i < nprob; ++i) kmax = probs[i].K > kmax ? probs[i].K : kmax;
-    const int ns = gemm_pick_stages(cfg, layout, kmax, stages);
+    int ns = gemm_pick_stages(cfg, layout, kmax, stages);
+    // One round of 128x128 tiles (the encoder's proj / fc2 / dX-proj at B=64: 480 workgroups): the plain double buffer beat the
+    // early-refill loop by 6-11 % for NT and for NN at K <= 768 in the same-process tile sweep (profiles/r01_f_tile_sweep_b64.txt),
+    // and tied elsewhere - with every workgroup resident at once there is no second round whose prologue the deeper prefetch hides.
+    if (stages < 0 && nprob == 1 && cfg == 0 && total <= 512 && probs[0].split_k == 1 &&
+        (layout == GEMM_NT || (layout == GEMM_NN && probs[0].K <= 768)))
+        ns = 4;
     // short-K single products with many tile rounds go to the persistent kernel (tile config 6 forces it, for tests);
     // BVC_GEMM_NO_PERSIST=1 keeps them on gemm_kernel (same-process A/B)
     // Same-box A/B at B=64 (profiles/r01_f_persist_ab_b64.txt): 128x128 persistent -12 ... -15 % on every eligible product; the

@@ -434,6 +434,7 @@ __global__ __launch_bounds__(256, LB) void gemm_kernel(const GemmGroup g) {
 
 // ------------------------------------------------------------------ host side
 static void tile_dims(int cfg, int& bm, int& bn) {
+    if (cfg == 10 || cfg == 11) { bm = 256; bn = cfg == 10 ? 256 : 128; return; }    // gemm8.hip
     bm = cfg == 2 ? 64 : 128;
     bn = cfg == 0 ? 128 : 64;
 }
@@ -447,6 +448,7 @@ static int tiles_for(const GemmProblem& p, int cfg) {
 int gemm_pick_tile(const GemmProblem* probs, int nprob, int tile_cfg) {
     if (tile_cfg == 6 || tile_cfg == 7) return tile_cfg - 6;     // the persistent kernel: 128x128 / 128x64 tiles
     if (tile_cfg == 9) return 0;                                  // persistent 128x128 with deferred stores
+    if (tile_cfg == 10 || tile_cfg == 11) return tile_cfg;        // gemm8.hip: 256x256 / 256x128
     if (tile_cfg >= 0) return tile_cfg;
     // Measured on MI355X (profiles/r01_b_microbench.json): a workgroup's speed is set by its L2->LDS fill
     // rate (~70 GB/s per CU), so the big tile (64 FLOP/B) wins once it alone covers the 256 CUs ~1.5x;
@@ -540,9 +542,37 @@ int launch_gemm_big_nt(const GemmProblem& p, int cfg, hipStream_t stream);   // 
 // gemm_persist.hip; returns 1 when the problem is not eligible.  defer: 0 = stores in the epilogue, 1 = deferred where possible,
 // 2 = deferred or not at all (tile config 9, tests)
 int launch_gemm_persist(const GemmGroup& g, GemmLayout layout, int cfg, hipStream_t stream, int defer);
+// gemm8.hip: 256 x bn tiles, one 512-thread workgroup per CU; returns 1 when the group is not eligible
+int launch_gemm8(const GemmGroup& g, GemmLayout layout, int bn, hipStream_t stream);
+
+// Which products go to the 256-row persistent kernel (gemm8.hip) when the caller leaves the tile choice open.  Fitted to the
+// same-process A/B of every product of the step (profiles/r02_a_gemm8_ab_b64.txt, tools/gemm8_ab.py): its K loop runs ~1.2 PFLOP/s
+// against ~0.8 for the 128 x 128 kernels, but it is ONE workgroup per CU - a launch needs about two full rounds of tiles, and
+// a heavy epilogue is not hidden by a second resident workgroup:
+//   * 256 x 256: bf16-output epilogues with >= 448 tiles (encoder fc1 / dX-fc2 at 64 clips, every wide decoder product),
+//     except GELU' at short K (the epilogue then outweighs the K loop);
+//   * 256 x 128: input-gradient products (NN, plain bf16 output) with K >= 1024 and >= 224 tiles.
+// Returns 10 / 11 (tile configs) or -1.
+static int pick_gemm8(const GemmProblem* probs, int nprob, GemmLayout layout) {
+    static const bool off = getenv("BVC_GEMM_NO_G8") != nullptr;
+    if (off || nprob != 1 || layout == GEMM_TN) return -1;
+    const GemmProblem& p = probs[0];
+    if (p.split_k != 1 || p.K % 64 != 0) return -1;
+    const bool bf = p.epi == EPI_BF16 || p.epi == EPI_GELU || p.epi == EPI_RELU;
+    const bool gated = p.epi == EPI_DGELU || p.epi == EPI_DRELU;
+    if (!bf && !gated) return -1;
+    const int t256 = ((p.M + 255) / 256) * ((p.N + 255) / 256), t128 = ((p.M + 255) / 256) * ((p.N + 127) / 128);
+    if (t256 >= 448 && !(gated && p.K <= 512) && !(layout == GEMM_NN && bf)) return 10;
+    if (layout == GEMM_NN && bf && p.K >= 1024 && t128 >= 224) return 11;
+    return -1;
+}
 
 int launch_gemm(const GemmProblem* probs, int nprob, GemmLayout layout, int tile_cfg, hipStream_t stream, int stages) {
     BVC_REQUIRE(nprob >= 1 && nprob <= kMaxGroup, "launch_gemm: nprob %d out of range", nprob);
+    if (tile_cfg < 0 && stages < 0) {
+        const int g8 = pick_gemm8(probs, nprob, layout);
+        if (g8 > 0) tile_cfg = g8;
+    }
     if ((tile_cfg >= 3 && tile_cfg <= 5) || tile_cfg == 8) {
         BVC_REQUIRE(nprob == 1 && layout == GEMM_NT, "launch_gemm: tile configs 3-5 (32-deep K steps) are NT, one problem");
         return launch_gemm_big_nt(probs[0], tile_cfg, stream);
@@ -574,6 +604,11 @@ int launch_gemm(const GemmProblem* probs, int nprob, GemmLayout layout, int tile
     }
     g.tile_start[nprob] = total;
     for (int i = nprob; i < kMaxGroup; ++i) { g.prob[i] = probs[0]; g.panel[i] = g.panel[0]; g.tile_start[i + 1] = total; }
+    if (cfg == 10 || cfg == 11) {
+        const int rc = launch_gemm8(g, layout, cfg == 10 ? 256 : 128, stream);
+        BVC_REQUIRE(rc != 1, "launch_gemm: tile configs 10 / 11 (256-row persistent kernel) do not take this problem");
+        return rc;
+    }
     int kmax = 0;
     for (int i = 0; i < nprob; ++i) kmax = probs[i].K > kmax ? probs[i].K : kmax;
     int ns = gemm_pick_stages(cfg, layout, kmax, stages);

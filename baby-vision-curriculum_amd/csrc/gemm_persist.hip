@@ -22,20 +22,6 @@
 
 namespace bvc {
 
-namespace {
-
-__device__ __forceinline__ void tile_of(int t, int tiles_m, int tiles_n, int G, int& tm, int& tn) {
-    const int full = (tiles_n / G) * G * tiles_m;
-    if (t < full) {
-        const int pn = t / (G * tiles_m), w = t - pn * G * tiles_m;
-        tm = w / G; tn = pn * G + (w - tm * G);
-    } else {
-        const int r = tiles_n % G, w = t - full;
-        tm = w / r; tn = (tiles_n - r) + (w - tm * r);
-    }
-}
-
-}  // namespace
 
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 

@@ -83,4 +83,16 @@ __device__ __forceinline__ bf16x8 read_frag(const char* lds, int rbase, int ks, 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
+// Tile id -> (row tile, column tile) of the panel walk: columns in panels of G tiles, rows fastest-but-one (see gemm_kernel).
+__device__ __forceinline__ void tile_of(int t, int tiles_m, int tiles_n, int G, int& tm, int& tn) {
+    const int full = (tiles_n / G) * G * tiles_m;
+    if (t < full) {
+        const int pn = t / (G * tiles_m), w = t - pn * G * tiles_m;
+        tm = w / G; tn = pn * G + (w - tm * G);
+    } else {
+        const int r = tiles_n % G, w = t - full;
+        tm = w / r; tn = (tiles_n - r) + (w - tm * r);
+    }
+}
+
 }  // namespace bvc

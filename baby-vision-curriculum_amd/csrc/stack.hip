@@ -149,6 +149,26 @@ int plan_dw(GemmProblem* g, int n) {
     static const int bm[3] = {128, 128, 64}, bn[3] = {128, 64, 64};
     int ksteps = 1 << 30;
     for (int i = 0; i < n; ++i) ksteps = std::min(ksteps, (g[i].K + 63) / 64);
+    // 256 x 128 tiles of the 256-row persistent kernel (gemm8.hip, tile config 11): one workgroup per CU walks its units as one
+    // stream of K tiles, so the split is chosen for ~230 units on the 256 CUs (encoder layer: 216 units unsplit, decoder layer:
+    // 57 x 4).  Same-process A/B at 64 clips (profiles/r02_a_gemm8_ab_b64.txt): encoder group 187 vs 241 us, decoder 469 vs 553.
+    static const bool no_g8 = getenv("BVC_GEMM_NO_G8") != nullptr;
+    if (!no_g8) {
+        int units = 0;
+        bool ok = true;
+        for (int i = 0; i < n; ++i) {
+            units += ((g[i].M + 255) / 256) * ((g[i].N + 127) / 128);
+            ok = ok && g[i].epi == EPI_F32 && g[i].a_bytes < 0x80000000u && g[i].b_bytes < 0x80000000u;
+        }
+        if (ok && units >= 40 && ksteps >= 16) {
+            int split = std::max(1, (232 + units / 2) / units);
+            split = std::min(split, std::max(1, ksteps / 16));
+            if (units * split >= 160) {
+                for (int i = 0; i < n; ++i) g[i].split_k = split;
+                return 11;
+            }
+        }
+    }
     const int cap = std::max(1, std::min(12, ksteps / 8));
     int tile = 2, split = 1;
     for (int t = 0; t < 3; ++t) {

@@ -1,110 +1,217 @@
 """Data-parallel wrapper for the flat-gradient step (one process per GPU, RCCL over xGMI).
 
-Replaces torch.nn.parallel.DistributedDataParallel at the reference's call site
-(pretraining/generative/pretrain_videomae.py:180-181: ``DDP(xmodel, device_ids=[rank],
-output_device=rank, find_unused_parameters=False)``; ``xmodel.module`` is used at :76,:318).
+Replaces torch.nn.parallel.DistributedDataParallel at the reference's call sites:
+  pretraining/generative/pretrain_videomae.py:180-181   DDP(xmodel, device_ids=[rank], output_device=rank, find_unused_parameters=False)
+  pretraining/contrastive/pretrain_simclr.py:227-228    the same for the SimCLR model (here: trunk + projection head)
+  pretraining/predictive/pretrain_jepa.py:302-304       DDP(encoder, static_graph=True), DDP(predictor, static_graph=True), DDP(target_encoder)
+(``xmodel.module`` is used at pretrain_videomae.py:76,318.)
 
-Why not torch's DDP: the step's backward is ONE library call that fills a flat gradient buffer, so
-there are no per-parameter autograd hooks to hang buckets on.  Instead the library reports, tail
-first, each contiguous gradient range whose kernels have been enqueued (bvc_bucket_fn in
-include/bvc.h); this wrapper coalesces ranges into buckets of >= bucket_cap_mb, fences the compute
-stream with an event and all-reduces the bucket on a dedicated communication stream, so the
-exchange overlaps the rest of backward.  The gradient buffer is contiguous, so every collective is
-a single large in-place all-reduce (no flatten / unflatten copies).  Ring all-reduce on xGMI is
-bound by one ~153 GB/s link per direction, hence few, large buckets.
+Why not torch's DDP: the step's backward is ONE library call per flat module that fills a flat gradient buffer, so there are
+no per-parameter autograd hooks to hang buckets on (torch's reducer would never see those gradients: they are published as
+views, not accumulated by autograd).  Instead the library reports, tail first, each contiguous gradient range whose kernels
+have been enqueued (bvc_bucket_fn in include/bvc.h); this wrapper coalesces ranges into buckets of >= bucket_cap_mb, fences
+the compute stream with an event and all-reduces the bucket in place on a dedicated communication stream, so the exchange
+overlaps the rest of backward.  Ring all-reduce on xGMI is bound by one ~153 GB/s link per direction, hence few, large buckets.
 
-The module protocol it relies on (implemented by VideoMAEForPreTraining):
-``flat_parameters()``, ``flat_grads()``, ``_bucket_hook``, ``_after_backward``.
+What may be wrapped:
+  * a flat module (VideoMAEForPreTraining, jepa.VisionTransformer, jepa.VisionTransformerPredictor): protocol
+    ``flat_parameters() / flat_grads() / _bucket_hook / _after_backward``;
+  * a COMPOSITE nn.Module that contains flat modules and ordinary parameters (simclr.SimCLRViT = flat ViT trunk + projection
+    head): every flat child gets the bucket hooks; the remaining ("loose") parameters are averaged as one coalesced
+    all-reduce as soon as autograd has accumulated the last of them;
+  * a module whose parameters never receive gradients (the JEPA target encoder): parameters are broadcast, nothing else.
 """
 from __future__ import annotations
+
+import time
 
 import torch
 import torch.distributed as dist
 import torch.nn as nn
 
 
+def _is_flat(m):
+    return hasattr(m, "flat_parameters") and hasattr(m, "flat_grads")
+
+
+class _FlatState:
+    """Bucket bookkeeping of one flat module."""
+
+    def __init__(self, module):
+        self.module = module
+        self.pending = None           # (lo, hi) coalesced range not yet reduced
+        self.fresh = True
+        self.reduced_ranges = []
+
+
 class DistributedDataParallel(nn.Module):
     def __init__(self, module, device_ids=None, output_device=None, find_unused_parameters=False,
-                 bucket_cap_mb=25.0, process_group=None, broadcast_parameters=True, force_collectives=False, **_ignored):
+                 bucket_cap_mb=25.0, process_group=None, broadcast_parameters=True, force_collectives=False,
+                 profile_buckets=False, **_ignored):
         super().__init__()
         if not (dist.is_available() and dist.is_initialized()):
             raise RuntimeError("DistributedDataParallel needs an initialised process group (dist.init_process_group)")
         self.module = module
         self.process_group = process_group
         self.world_size = dist.get_world_size(process_group)
-        self.force_collectives = force_collectives   # issue the collectives even with one rank (tests)
+        self.force_collectives = force_collectives   # issue the collectives even with one rank (tests, one-GPU rehearsal)
         self.bucket_elems = int(bucket_cap_mb * 1024 * 1024 / 4)
-        self._pending = None          # (lo, hi) coalesced range not yet reduced
         self._comm_stream = None
-        self._works = []
-        self.reduced_ranges = []      # ranges all-reduced during the last backward (introspection / tests)
-        self._fresh = True
+        self._events = []             # pre-allocated fence events, reused round robin (one per bucket in flight)
+        self._ev_next = 0
+        self.profile_buckets = profile_buckets
+        self._timed = []              # (bytes, start event, end event) of the buckets of the current backward
+        self.bucket_log = []          # per finished backward: [(bytes, ms)]
         self._device = None
         if device_ids:
             self._device = torch.device("cuda", device_ids[0]) if isinstance(device_ids[0], int) else torch.device(device_ids[0])
-        if hasattr(module, "_ensure_flat") and self._device is not None:
-            module._ensure_flat(self._device)
+
+        # flat modules inside `module` (itself included) and the parameters that belong to none of them
+        mods = list(module.modules()) if isinstance(module, nn.Module) else [module]
+        self._flats = [_FlatState(m) for m in mods if _is_flat(m)]
+        owned = set()
+        for st in self._flats:
+            m = st.module
+            if hasattr(m, "_ensure_flat") and self._device is not None:
+                m._ensure_flat(self._device)
+            if isinstance(m, nn.Module):
+                owned.update(id(p) for p in m.parameters())
+        self._loose = [p for p in module.parameters() if id(p) not in owned] if isinstance(module, nn.Module) else []
+        self._loose_grad = [p for p in self._loose if p.requires_grad]
+        self._loose_seen = 0
         if broadcast_parameters:
             self._broadcast()
-        module._bucket_hook = self._on_range
-        module._after_backward = self._finish
+        for st in self._flats:
+            st.module._bucket_hook = (lambda off, cnt, _st=st: self._on_range(_st, off, cnt))
+            st.module._after_backward = (lambda _st=st: self._finish(_st))
+        self._loose_handles = [p.register_post_accumulate_grad_hook(self._on_loose_grad) for p in self._loose_grad]
+
+    # back-compat introspection: ranges reduced during the last backward of the (first) flat module
+    @property
+    def reduced_ranges(self):
+        return self._flats[0].reduced_ranges if self._flats else []
 
     # module-state sync from rank 0, what DDP's constructor does (C2 in SURVEY.md 2.3)
     def _broadcast(self):
-        flat = self.module.flat_parameters()
-        dist.broadcast(flat, src=0, group=self.process_group)
+        for st in self._flats:
+            dist.broadcast(st.module.flat_parameters(), src=0, group=self.process_group)
+        tensors = [p.data for p in self._loose]
+        if isinstance(self.module, nn.Module):
+            tensors += [b.data for b in self.module.buffers() if b.is_floating_point()]
+        if tensors:
+            flat = torch.cat([t.reshape(-1).float() for t in tensors])
+            dist.broadcast(flat, src=0, group=self.process_group)
+            o = 0
+            for t in tensors:
+                n = t.numel()
+                t.copy_(flat[o:o + n].view_as(t))
+                o += n
 
     def forward(self, *args, **kwargs):
         return self.module(*args, **kwargs)
 
     # ---- gradient exchange
-    def _use_streams(self, t):
-        return t.is_cuda
+    def _active(self):
+        return self.world_size > 1 or self.force_collectives
 
-    def _on_range(self, offset, count):
-        """Host callback from the library: gradients [offset, offset+count) are enqueued."""
-        lo, hi = offset, offset + count
-        if self._fresh:
-            self.reduced_ranges, self._fresh = [], False
-        if self._pending is None:
-            self._pending = (lo, hi)
-        else:
-            plo, phi = self._pending
-            if hi == plo:            # ranges arrive tail-first and contiguous
-                self._pending = (lo, phi)
-            elif lo == phi:
-                self._pending = (plo, hi)
-            else:                    # not adjacent: flush what we have
-                self._reduce(plo, phi)
-                self._pending = (lo, hi)
-        plo, phi = self._pending
-        if phi - plo >= self.bucket_elems:
-            self._reduce(plo, phi)
-            self._pending = None
+    def _fence_event(self):
+        if len(self._events) < 8:
+            self._events.append(torch.cuda.Event())
+            return self._events[-1]
+        ev = self._events[self._ev_next % len(self._events)]
+        self._ev_next += 1
+        return ev
 
-    def _reduce(self, lo, hi):
-        if self.world_size == 1 and not self.force_collectives:
-            self.reduced_ranges.append((lo, hi))
-            return
-        g = self.module.flat_grads()[lo:hi]
-        if self._use_streams(g):
+    def _all_reduce_avg(self, g):
+        """In-place mean over ranks of a contiguous gradient tensor, on the communication stream when it lives on a GPU."""
+        if g.is_cuda:
             if self._comm_stream is None:
                 self._comm_stream = torch.cuda.Stream(device=g.device)
-            ev = torch.cuda.Event()
+            ev = self._fence_event()
             ev.record(torch.cuda.current_stream(g.device))
             self._comm_stream.wait_event(ev)
             with torch.cuda.stream(self._comm_stream):
+                if self.profile_buckets:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(self._comm_stream)
                 dist.all_reduce(g, op=dist.ReduceOp.AVG, group=self.process_group)   # ncclAvg on RCCL
+                if self.profile_buckets:
+                    e1.record(self._comm_stream)
+                    self._timed.append((g.numel() * g.element_size(), e0, e1))
         else:
             dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.process_group)       # gloo has no AVG
             g.div_(self.world_size)
-        self.reduced_ranges.append((lo, hi))
 
-    def _finish(self):
-        """End of backward: flush the last bucket and make the compute stream wait for the exchange."""
-        if self._pending is not None:
-            self._reduce(*self._pending)
-            self._pending = None
+    def _on_range(self, st, offset, count):
+        """Host callback from the library: gradients [offset, offset+count) of flat module `st` are enqueued."""
+        lo, hi = offset, offset + count
+        if st.fresh:
+            st.reduced_ranges, st.fresh = [], False
+        if st.pending is None:
+            st.pending = (lo, hi)
+        else:
+            plo, phi = st.pending
+            if hi == plo:            # ranges arrive tail-first and contiguous
+                st.pending = (lo, phi)
+            elif lo == phi:
+                st.pending = (plo, hi)
+            else:                    # not adjacent: flush what we have
+                self._reduce(st, plo, phi)
+                st.pending = (lo, hi)
+        plo, phi = st.pending
+        if phi - plo >= self.bucket_elems:
+            self._reduce(st, plo, phi)
+            st.pending = None
+
+    def _reduce(self, st, lo, hi):
+        if self._active():
+            self._all_reduce_avg(st.module.flat_grads()[lo:hi])
+        st.reduced_ranges.append((lo, hi))
+
+    def _join(self, device):
         if self._comm_stream is not None:
-            torch.cuda.current_stream(self._comm_stream.device).wait_stream(self._comm_stream)
-        self._fresh = True
+            torch.cuda.current_stream(device).wait_stream(self._comm_stream)
+
+    def _finish(self, st):
+        """End of one flat module's backward: flush its last bucket and make the compute stream wait for the exchange."""
+        if st.pending is not None:
+            self._reduce(st, *st.pending)
+            st.pending = None
+        if self._comm_stream is not None:
+            self._join(self._comm_stream.device)
+        st.fresh = True
+        if self.profile_buckets and self._timed:
+            torch.cuda.current_stream().synchronize()
+            self.bucket_log.append([(nbytes, e0.elapsed_time(e1)) for nbytes, e0, e1 in self._timed])
+            self._timed = []
+
+    def _on_loose_grad(self, _param):
+        """autograd has accumulated one more ordinary parameter; after the last one, average them all as ONE collective."""
+        self._loose_seen += 1
+        if self._loose_seen < len(self._loose_grad):
+            return
+        self._loose_seen = 0
+        if not self._active():
+            return
+        grads = [p.grad for p in self._loose_grad if p.grad is not None]
+        if not grads:
+            return
+        flat = torch.cat([g.reshape(-1).float() for g in grads])
+        self._all_reduce_avg(flat)
+        if flat.is_cuda:
+            self._join(flat.device)      # a few MB: not worth overlapping, and the copies below read it
+        o = 0
+        for g in grads:
+            n = g.numel()
+            g.copy_(flat[o:o + n].view_as(g))
+            o += n
+
+    # ---- reporting (bench.py): algorithm bandwidth and ring bus bandwidth per bucket of the logged backwards
+    def bucket_report(self):
+        out = []
+        n = self.world_size
+        for step in self.bucket_log:
+            out.append([{"mb": round(b / 1e6, 2), "ms": round(ms, 4),
+                         "algbw_gbs": round(b / ms / 1e6, 1) if ms > 0 else None,
+                         "busbw_gbs": round(b / ms / 1e6 * 2 * (n - 1) / n, 1) if ms > 0 else None} for b, ms in step])
+        return out

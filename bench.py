@@ -25,6 +25,12 @@ import __graft_entry__ as ge  # noqa: E402
 
 GFLOP_PER_CLIP = 202.295          # algorithmic fwd+bwd FLOPs per clip, BASELINE.md section 3
 PEAK_BF16_TFLOPS = 2500.0         # dense bf16 MFMA peak, MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0             # HBM3E peak, MI355X_MICROARCH.md (6.29 TB/s measured by a float4 copy)
+
+
+def library_hash():
+    """Content hash of the HIP sources the loaded library was built from (what profiles/traffic_b*.json are stamped with)."""
+    return ge._source_hash()
 
 
 def measured_traffic(batch):
@@ -38,6 +44,9 @@ def measured_traffic(batch):
     try:
         with open(path) as f:
             t = json.load(f)
+        if t.get("source_hash") != library_hash():
+            # measured on other kernels than the ones that just ran: say so instead of printing stale bytes
+            return None, os.path.relpath(path, ROOT) + " (stale: source hash differs)"
         return float(t["hbm_bytes_per_step"]), os.path.relpath(path, ROOT)
     except (OSError, KeyError, ValueError):
         return None, None
@@ -68,9 +77,23 @@ def dominant_kernel_probe(bvc, batch, device):
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / iters
     flops, nbytes = 2.0 * M * N * K, 2.0 * (M * K + N * K + 2 * M * N)
-    return {"name": "gemm_persist_kernel<128, false> (decoder fc1 + GELU)", "shape": [M, N, K], "launch_us": round(us, 1),
+    t_mfma, t_hbm = flops / (PEAK_BF16_TFLOPS * 1e6), nbytes / (PEAK_HBM_GBS * 1e3)     # us at either roof
+    bound = "hbm" if t_hbm > t_mfma else "mfma"
+    return {"name": "decoder fc1 + bias + GELU (gemm8_kernel<256,NT> when >= 448 tiles, else gemm_persist_kernel<128,NT>)",
+            "shape": [M, N, K], "launch_us": round(us, 1), "launches_per_step": 4,
             "achieved_tflops": round(flops / us / 1e6, 1), "frac_mfma": round(flops / us / 1e6 / PEAK_BF16_TFLOPS, 4),
-            "algorithmic_gb_per_s": round(nbytes / us / 1e3, 1)}
+            "algorithmic_bytes": nbytes, "algorithmic_gb_per_s": round(nbytes / us / 1e3, 1),
+            "frac_hbm": round(nbytes / us / 1e3 / PEAK_HBM_GBS, 4), "bound": bound,
+            "frac": round(max(t_mfma, t_hbm) / us, 4)}
+
+
+def load_launcher():
+    """baby-vision-curriculum_amd/launch.py by path: the launcher parent must not import the package (which maps the HIP library)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bvc_launch", os.path.join(ROOT, "baby-vision-curriculum_amd", "launch.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
 
 
 def synthetic_clips(batch, seed, device):
@@ -130,14 +153,23 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--torch-sgd", action="store_true", help="use torch.optim.SGD instead of the fused HIP update")
     ap.add_argument("--per-step", action="store_true", help="diagnostic: per-step HIP-event and host-enqueue times to stderr")
+    ap.add_argument("--stream-input", action="store_true",
+                    help="feed every step a fresh uint8 batch from pinned host memory through the upload ring (copy stream + events) "
+                         "instead of re-using clips resident in HBM; reported beside the resident-input number, never as `value`")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher (as the reference's __main__ does with mp.spawn,
+        # pretrain_videomae.py:509-513).  Nothing in this process has touched the GPU; N fresh interpreters run the ranks.
+        sys.exit(load_launcher().spawn_ranks([os.path.abspath(__file__), *sys.argv[1:]], args.gpus))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s)")
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"bench.py: rank {rank} needs GPU {local_rank}, {torch.cuda.device_count()} visible")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_ddp = world > 1 or bool(os.environ.get("BVC_FORCE_DDP"))   # the env switch exercises the RCCL path on one GPU
@@ -168,8 +200,19 @@ def main():
     # done as one read-only pass over the flat gradient buffer (--torch-sgd also switches back to the stock scaler)
     scaler = torch.amp.GradScaler("cuda") if args.torch_sgd else bvc.amp.GradScaler("cuda")
     B = args.batch
-    clips = synthetic_clips(B, 1234 + rank, dev)
     mask_gen = bvc.TubeMaskingGenerator((8, 14, 14), 0.9, rng=np.random.RandomState(1234 + rank))
+    ring, host_batches = None, []
+    if args.stream_input:
+        # what a DataLoader(pin_memory=True) of uint8 frames hands over: three different pinned batches, cycled; every step's
+        # clips cross PCIe on the copy stream while the previous step computes (baby-vision-curriculum_amd/input.py)
+        g = torch.Generator().manual_seed(1234 + rank)
+        host_batches = [torch.randint(0, 256, (B, 16, 3, 224, 224), generator=g, dtype=torch.uint8).pin_memory() for _ in range(3)]
+        ring = bvc.ClipUploadRing((B, 16, 3, 224, 224), dev, depth=3)
+        ring.stage(host_batches[0])
+        clips = None
+    else:
+        clips = synthetic_clips(B, 1234 + rank, dev)
+    nstep = [0]
 
     def step():
         bool_masked = np.zeros((B, 1568))
@@ -177,13 +220,24 @@ def main():
             bool_masked[i, :] = mask_gen()
         # pinned + non_blocking: a pageable .to(device) makes the host wait for the stream, so it could not run ahead
         bool_masked_pos = torch.from_numpy(bool_masked).bool().pin_memory().to(dev, non_blocking=True)
+        if ring is not None:
+            nstep[0] += 1
+            ring.stage(host_batches[nstep[0] % len(host_batches)])     # the NEXT step's clips start crossing PCIe now
+            x = ring.get()
+        else:
+            x = clips
         opt.zero_grad()
         with torch.autocast("cuda", dtype=torch.bfloat16):
-            out = xmodel(clips, bool_masked_pos=bool_masked_pos)
-            loss = bvc.AllReduce.apply(out.loss)
-        scaler.scale(loss).backward()
+            out = xmodel(x, bool_masked_pos=bool_masked_pos)
+        # the reference reduces the loss before backward (pretrain_videomae.py:303,312); AllReduce's backward is the identity
+        # (ddputils.py:64-68), so the gradients are those of the LOCAL loss either way.  Here backward is enqueued first and
+        # the scalar all-reduce (only logging reads it) follows: the collective no longer sits between forward and backward.
+        scaler.scale(out.loss).backward()
+        loss = bvc.AllReduce.apply(out.loss.detach())
         scaler.step(opt)
         scaler.update()
+        if ring is not None:
+            ring.release()
         return loss
 
     for _ in range(args.warmup):
@@ -218,6 +272,21 @@ def main():
     if use_ddp:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t)
+    comm = None
+    if use_ddp:
+        # two more steps OUTSIDE the timed region with per-bucket events on the communication stream: bytes, time, ring bus bandwidth
+        xmodel.profile_buckets = True
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        rep = xmodel.bucket_report()
+        comm = {"backend": "rccl (torch.distributed nccl)", "ranks": dist.get_world_size(), "bucket_cap_mb": 25.0,
+                "buckets_last_step": rep[-1] if rep else []}
+        xmodel.profile_buckets = False
+    stream_info = None
+    if ring is not None:
+        stream_info = {"bytes_per_step": B * 16 * 3 * 224 * 224, "ring_depth": ring.depth,
+                       "h2d_gb_per_s_sustained": round(B * 16 * 3 * 224 * 224 * args.steps / dt / 1e9, 2)}
 
     if rank == 0:
         clips_s = world * B * args.steps / dt
@@ -235,11 +304,19 @@ def main():
                        "weights": "random init N(0,0.02), seed 0", "final_loss": round(final_loss, 5)},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "one training step = the fwd+bwd kernel sequence of libbvc_hip.so on the compute stream",
+                         "scope": "one training step = the fwd+bwd kernel sequence of libbvc_hip.so on the compute stream",
                          "flops_per_launch": GFLOP_PER_CLIP * 1e9 * B, "launch_ms": round(step_ms_gpu, 4)},
         }
         if world == 1:
-            line["roofline"]["dominant_kernel"] = dominant_kernel_probe(bvc, B, dev)
+            # the dominant kernel of the step, timed alone in this run: named at the top level of `roofline`, with the bound its
+            # own numbers say (fc1 + GELU at K = 384 writes two M x 1536 bf16 outputs: HBM-bound, not MFMA-bound)
+            dk = dominant_kernel_probe(bvc, B, dev)
+            line["roofline"].update({"kernel": dk["name"], "launch_us": dk["launch_us"], "kernel_bound": dk["bound"],
+                                     "kernel_frac": dk["frac"], "dominant_kernel": dk})
+        if comm is not None:
+            line["comm"] = comm
+        if stream_info is not None:
+            line["input_stream"] = stream_info
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)

@@ -618,3 +618,130 @@ def test_bvc_gradscaler_matches_torch_gradscaler():
         outs.append((flat.clone(), scales))
     assert outs[0][1] == outs[1][1]
     assert torch.equal(outs[0][0], outs[1][0])
+
+
+# --------------------------------------------------------------------------- GEMM, 256-row persistent kernel (csrc/gemm8.hip)
+# tile 10 = 256 x 256 (bf16-output epilogues and weight gradients), tile 11 = 256 x 128 (every epilogue)
+G8_SHAPES = [(256, 256, 128), (200, 192, 256), (520, 384, 384), (136, 72, 192), (2560, 768, 768), (1000, 1152, 64), (10240, 2304, 256)]
+
+
+@pytest.mark.parametrize("layout", [G.NT, G.NN, G.TN])
+@pytest.mark.parametrize("M,N,K", G8_SHAPES)
+def test_gemm8_f32(layout, M, N, K):
+    # ragged M / N, one to 360 units per launch (more units than CUs: the stream crosses unit boundaries), odd K-tile counts
+    if layout == G.TN:
+        M, N, K = N, (M // 8) * 8 if M < 3000 else 768, M     # weight-gradient shape: long contraction
+        M = (M // 8) * 8
+    sa, sb = _shapes(layout, M, N, K)
+    A = G.bf16_randn(*sa, seed=1)
+    B = G.bf16_randn(*sb, seed=2)
+    ref = _ref_gemm(A, B, layout)
+    for tile in ((10, 11) if layout == G.TN else (11,)):
+        C = torch.full((M, N), float("nan"), device=dev)
+        G.run_gemm([G.gemm_desc(A, B, M, N, K, G.EPI["F32"], C)], layout, tile)
+        torch.cuda.synchronize()
+        assert torch.isfinite(C).all(), (layout, tile, M, N, K)
+        assert G.rel_err(C, ref) < 1e-5, (layout, tile, M, N, K)
+
+
+@pytest.mark.parametrize("layout", [G.NT, G.NN])
+@pytest.mark.parametrize("tile", [10, 11])
+@pytest.mark.parametrize("M,N,K", G8_SHAPES)
+def test_gemm8_bf16_matches_per_tile_kernel_bitwise(layout, tile, M, N, K):
+    # same K order per output element and the same epilogue arithmetic as gemm_kernel: bit-identical bf16 results
+    sa, sb = _shapes(layout, M, N, K)
+    A, B = G.bf16_randn(*sa, seed=3), G.bf16_randn(*sb, seed=4, scale=0.1)
+    bias = torch.randn(N, device=dev)
+    C0 = torch.zeros(M, N, device=dev, dtype=torch.bfloat16)
+    C1 = torch.full((M, N), 7.0, device=dev, dtype=torch.bfloat16)
+    G.run_gemm([G.gemm_desc(A, B, M, N, K, G.EPI["BF16"], C0, bias=bias)], layout, 0)
+    G.run_gemm([G.gemm_desc(A, B, M, N, K, G.EPI["BF16"], C1, bias=bias)], layout, tile)
+    torch.cuda.synchronize()
+    assert torch.equal(C0.view(torch.int16), C1.view(torch.int16)), (layout, tile, M, N, K)
+    assert G.rel_err(C1.float(), _ref_gemm(A, B, layout) + bias) < 4e-3
+
+
+@pytest.mark.parametrize("tile", [10, 11])
+def test_gemm8_epilogues(tile):
+    M, N, K = 1100, 512, 384
+    A, W = G.bf16_randn(M, K, seed=20), G.bf16_randn(N, K, seed=21, scale=0.1)
+    bias = torch.randn(N, device=dev)
+    acc = A.float() @ W.float().t()
+    pre = torch.zeros(M, N, device=dev, dtype=torch.bfloat16)
+    act = torch.zeros_like(pre)
+    G.run_gemm([G.gemm_desc(A, W, M, N, K, G.EPI["GELU"], pre, C2=act, bias=bias)], G.NT, tile)
+    assert G.rel_err(pre.float(), acc + bias) < 4e-3
+    assert G.rel_err(act.float(), torch.nn.functional.gelu(acc + bias)) < 4e-3
+    # DGELU (NN): dh = (dy W2) * gelu'(pre)
+    I = 768
+    dy, W2 = G.bf16_randn(M, N, seed=22), G.bf16_randn(N, I, seed=23, scale=0.1)
+    prei = G.bf16_randn(M, I, seed=24)
+    dh = torch.zeros(M, I, device=dev, dtype=torch.bfloat16)
+    G.run_gemm([G.gemm_desc(dy, W2, M, I, N, G.EPI["DGELU"], dh, aux=prei)], G.NN, tile)
+    x = prei.float().requires_grad_(True)
+    torch.nn.functional.gelu(x).sum().backward()
+    assert G.rel_err(dh.float(), (dy.float() @ W2.float()) * x.grad) < 4e-3
+    if tile == 10:
+        return
+    # the f32-side epilogues run on 256 x 128 tiles only
+    resid = torch.randn(M, N, device=dev)
+    out = torch.zeros(M, N, device=dev)
+    G.run_gemm([G.gemm_desc(A, W, M, N, K, G.EPI["RESID"], out, bias=bias, resid=resid)], G.NT, tile)
+    assert G.rel_err(out, resid + acc + bias) < 1e-5
+    inpl = resid.clone()
+    G.run_gemm([G.gemm_desc(A, W, M, N, K, G.EPI["RESID"], inpl, bias=bias, resid=inpl)], G.NT, tile)
+    assert G.rel_err(inpl, resid + acc + bias) < 1e-5
+    tok = torch.randint(0, 50, (M,), device=dev, dtype=torch.int32)
+    pos = torch.randn(50, N, device=dev)
+    out = torch.zeros(M, N, device=dev)
+    G.run_gemm([G.gemm_desc(A, W, M, N, K, G.EPI["POS"], out, bias=bias, rowtok=tok, pos=pos)], G.NT, tile)
+    assert G.rel_err(out, acc + bias + pos[tok.long()]) < 1e-5
+    rin, rout = 100, 150
+    big = torch.zeros(M // rin * rout, N, device=dev)
+    G.run_gemm([G.gemm_desc(A, W, M, N, K, G.EPI["E2D"], big, rowtok=tok, pos=pos, rin=rin, rout=rout)], G.NT, tile)
+    ref = torch.zeros_like(big)
+    m = torch.arange(M, device=dev)
+    ref[(m // rin) * rout + m % rin] = acc + pos[tok.long()]
+    assert G.rel_err(big, ref) < 1e-5
+    labels = torch.randn(M, N, device=dev)
+    diff = torch.zeros(M, N, device=dev, dtype=torch.bfloat16)
+    logits = torch.zeros(M, N, device=dev)
+    d = G.gemm_desc(A, W, M, N, K, G.EPI["LOSS"], diff, C2=logits, bias=bias, labels=labels)
+    nt = L.lib().bvc_op_gemm_num_tiles(d, tile)
+    assert nt == ((M + 255) // 256) * (N // 128)
+    partial = torch.full((nt,), float("nan"), device=dev)
+    d.partial = partial.data_ptr()
+    G.run_gemm([d], G.NT, tile)
+    assert G.rel_err(logits, acc + bias) < 1e-5
+    assert G.rel_err(diff.float(), acc + bias - labels) < 4e-3
+    want = float(((acc + bias - labels) ** 2).sum())
+    assert abs(float(partial.sum()) - want) / want < 1e-5
+    s = torch.tensor([3.0], device=dev)
+    o32 = torch.zeros(M, N, device=dev)
+    o16 = torch.zeros(M, N, device=dev, dtype=torch.bfloat16)
+    G.run_gemm([G.gemm_desc(A, W, M, N, K, G.EPI["F32_BF16"], o32, C2=o16, alpha=0.5, alpha_dev=s)], G.NT, tile)
+    assert G.rel_err(o32, 1.5 * acc) < 1e-5 and G.rel_err(o16.float(), 1.5 * acc) < 4e-3
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("tile", [10, 11])
+@pytest.mark.parametrize("split", [1, 3, 4])
+def test_gemm8_weight_gradient_group(tile, split):
+    # the four weight gradients of one layer in one launch, fused bias gradients, split-K atomics, ragged token count
+    Mtok, D, I = 5000, 384, 1536
+    dy, act = G.bf16_randn(Mtok, D, seed=7), G.bf16_randn(Mtok, I, seed=8)
+    dh, ln2 = G.bf16_randn(Mtok, I, seed=9), G.bf16_randn(Mtok, D, seed=10)
+    dqkv, ln1 = G.bf16_randn(Mtok, 3 * D, seed=11), G.bf16_randn(Mtok, D, seed=12)
+    outs = [torch.zeros(D, I, device=dev), torch.zeros(I, D, device=dev), torch.zeros(D, D, device=dev), torch.zeros(3 * D, D, device=dev)]
+    bs = [torch.zeros(D, device=dev), torch.zeros(I, device=dev), torch.zeros(D, device=dev), torch.zeros(3 * D, device=dev)]
+    descs = [G.gemm_desc(dy, act, D, I, Mtok, G.EPI["F32"], outs[0], rowsum=bs[0], split_k=split),
+             G.gemm_desc(dh, ln2, I, D, Mtok, G.EPI["F32"], outs[1], rowsum=bs[1], split_k=split),
+             G.gemm_desc(dy, ln2, D, D, Mtok, G.EPI["F32"], outs[2], rowsum=bs[2], split_k=split),
+             G.gemm_desc(dqkv, ln1, 3 * D, D, Mtok, G.EPI["F32"], outs[3], rowsum=bs[3], split_k=split)]
+    G.run_gemm(descs, G.TN, tile)
+    torch.cuda.synchronize()
+    refs = [dy.float().t() @ act.float(), dh.float().t() @ ln2.float(), dy.float().t() @ ln2.float(), dqkv.float().t() @ ln1.float()]
+    for o, r in zip(outs, refs):
+        assert G.rel_err(o, r) < 1e-5
+    for b, x in zip(bs, (dy, dh, dy, dqkv)):
+        assert float((b - x.float().sum(0)).abs().max()) < 2e-2 * math.sqrt(Mtok / 1000.0)

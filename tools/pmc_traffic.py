@@ -10,8 +10,12 @@ usage: python tools/pmc_traffic.py <fetch_dir> <write_dir> <steps> <batch> <out.
 import csv
 import glob
 import json
+import os
 import sys
 from collections import defaultdict
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import __graft_entry__ as ge  # noqa: E402
 
 
 def per_step(d, counter, steps):
@@ -44,6 +48,7 @@ def main():
         "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) around bench.py",
         "corrections": "KiB -> bytes; FETCH_SIZE x2 on gfx950 (128-B requests tallied at 64 B)",
         "batch": batch, "steps_averaged": steps,
+        "source_hash": ge._source_hash(),      # bench.py reports these bytes only while the library sources are unchanged
         "read_bytes_per_step": sum(rd.values()), "write_bytes_per_step": sum(wr.values()),
         "hbm_bytes_per_step": sum(rd.values()) + sum(wr.values()),
         "by_kernel_GB": {k: {"read": round(rd.get(k, 0) / 1e9, 4), "write": round(wr.get(k, 0) / 1e9, 4)} for k in fams[:40]},

@@ -111,6 +111,7 @@ SYMBOLS = {
     "bvc_predictor_destroy": (None, [c_void_p]),
     "bvc_predictor_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "bvc_predictor_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "bvc_predictor_backward_cb": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, BUCKET_FN, c_void_p, c_void_p]),
     "bvc_op_target_select": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "bvc_op_smooth_l1_workspace": (c_int, [c_int64]),
     "bvc_op_smooth_l1_fwd": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),

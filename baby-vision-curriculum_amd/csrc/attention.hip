@@ -509,7 +509,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const bf16_t* __r
 
 // ============================================================================ host launchers
 // BVC_ATTN_PLAIN_GRID=1 switches the XCD-aware block map off (same-run A/B in tools/microbench.py; read per launch)
-static int xcd_remap() { return getenv("BVC_ATTN_PLAIN_GRID") == nullptr; }
+static int xcd_remap() {
+#ifdef BVC_EXPERIMENTS      // same-process A/B of the XCD-aware block map (tools/microbench.py)
+    return getenv("BVC_ATTN_PLAIN_GRID") == nullptr;
+#else
+    return 1;
+#endif
+}
 
 template <int HD>
 static int fwd_hd(const bf16_t* qkv, bf16_t* ctx, float* lse, int B, int N, int H, hipStream_t stream, float sm_scale) {

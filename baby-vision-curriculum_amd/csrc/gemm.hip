@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256, LB) void gemm_kernel(const GemmGroup g) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
-    if ((g.dbg & 2) && ((blockIdx.x >> 3) & 1)) __builtin_amdgcn_s_sleep(100);
+    if (BVC_DBG(g, 2) && ((blockIdx.x >> 3) & 1)) __builtin_amdgcn_s_sleep(100);
 
     // XCD-aware remap (bijective for any grid size): XCD x owns a contiguous run of logical ids
     const int nb = gridDim.x, bid = blockIdx.x;
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256, LB) void gemm_kernel(const GemmGroup g) {
                 for (int j = 0; j < TN; ++j) bfr[ks][j] = read_frag<BN, BT>(slot + A_BYTES, wn * WN + 16 * j, ks, lane);
             }
             auto mfma_half = [&](int ks) {
-                if (g.dbg & 16) return;     // experiment: loads and barriers only
+                if (BVC_DBG(g, 16)) return;     // experiment: loads and barriers only
     #pragma unroll
                 for (int i = 0; i < TM; ++i)
     #pragma unroll
@@ -196,13 +196,13 @@ __global__ __launch_bounds__(256, LB) void gemm_kernel(const GemmGroup g) {
             if (it + 2 < nt) {
                 // own fragment reads retired, then the barrier: every wave is done with this slot -> refill it
                 asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-                if (!(g.dbg & 32)) stage_tile<BM, AT>(ra, m0, (t0 + it + 2) * BK, p.lda, slot, wave, lane);
-                if (!(g.dbg & (8 | 32))) stage_tile<BN, BT>(rb, n0, (t0 + it + 2) * BK, p.ldb, slot + A_BYTES, wave, lane);
+                if (!BVC_DBG(g, 32)) stage_tile<BM, AT>(ra, m0, (t0 + it + 2) * BK, p.lda, slot, wave, lane);
+                if (!BVC_DBG(g, 8 | 32)) stage_tile<BN, BT>(rb, n0, (t0 + it + 2) * BK, p.ldb, slot + A_BYTES, wave, lane);
             }
             mfma_half(1);
             if (it + 1 < nt) {
                 // K-step it+1 must have landed everywhere before the next iteration reads it; the refill just issued may fly on
-                if (it + 2 < nt && !(g.dbg & (8 | 32))) wait_vmcnt<DMA_PER_STAGE>(); else wait_vmcnt<0>();
+                if (it + 2 < nt && !BVC_DBG(g, 8 | 32)) wait_vmcnt<DMA_PER_STAGE>(); else wait_vmcnt<0>();
                 asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             }
         }
@@ -300,7 +300,7 @@ __global__ __launch_bounds__(256, LB) void gemm_kernel(const GemmGroup g) {
                 *reinterpret_cast<f32x4*>(dst + 4) = f32x4{v[4], v[5], v[6], v[7]};
             };
             auto store_bf16 = [&](void* base, size_t at, const float* w) {
-                if (g.dbg & 1) return;
+                if (BVC_DBG(g, 1)) return;
                 *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(base) + at) =
                     uint4{pack2bf(w[0], w[1]), pack2bf(w[2], w[3]), pack2bf(w[4], w[5]), pack2bf(w[6], w[7])};
             };
@@ -471,7 +471,7 @@ int gemm_pick_tile(const GemmProblem* probs, int nprob, int tile_cfg) {
 // the problem; with panels of G column tiles the A rows are fetched once per panel, and the B panel is fetched once if it fits
 // ~2 MiB of the L2 and otherwise once per resident wave of 64 workgroups.  Candidates: no panels, or the widest panel that fits.
 static int pick_panel(const GemmProblem& p, int cfg, GemmLayout layout) {
-    if (getenv("BVC_GEMM_LEGACY_WALK") != nullptr) return 0;     // read per launch: same-process A/B (tools/microbench.py)
+    if (BVC_EXP_ENV("BVC_GEMM_LEGACY_WALK") != nullptr) return 0;     // experiments build: read per launch for same-process A/Bs
     // Same-box A/B at B=64 (profiles/r01_e_walk_ab_b64.txt): the panel walk is worth +5 % on the encoder fc1 shape and is
     // neutral elsewhere for NT / NN; the split-K weight-gradient launches are 2-10 % FASTER with the legacy walk (splits
     // fastest, short side first) although it fetches more - the Infinity Cache absorbs the re-reads - so TN keeps it.
@@ -574,14 +574,18 @@ int launch_gemm(const GemmProblem* probs, int nprob, GemmLayout layout, int tile
         if (g8 > 0) tile_cfg = g8;
     }
     if ((tile_cfg >= 3 && tile_cfg <= 5) || tile_cfg == 8) {
+#ifdef BVC_EXPERIMENTS
         BVC_REQUIRE(nprob == 1 && layout == GEMM_NT, "launch_gemm: tile configs 3-5 (32-deep K steps) are NT, one problem");
         return launch_gemm_big_nt(probs[0], tile_cfg, stream);
+#else
+        BVC_REQUIRE(false, "launch_gemm: tile configs 3-5 / 8 exist only in a -DBVC_EXPERIMENTS build (csrc/gemm_big.hip)");
+#endif
     }
     const int cfg = gemm_pick_tile(probs, nprob, tile_cfg);
     GemmGroup g;
     g.nprob = nprob;
     {
-        const char* e = getenv("BVC_GEMM_DEBUG");
+        const char* e = BVC_EXP_ENV("BVC_GEMM_DEBUG");
         g.dbg = e ? atoi(e) : 0;
     }
     int total = 0;
@@ -624,12 +628,12 @@ int launch_gemm(const GemmProblem* probs, int nprob, GemmLayout layout, int tile
     // 128x64 form wins only at short K (decoder proj, K=384: -5 %) and LOSES 6-16 % at K >= 1152, where the per-tile kernel's
     // third resident workgroup per CU matters more than the chaining - so it is taken up to K = 512 only.
     const bool auto_persist = tile_cfg < 0 && stages < 3 && g.dbg == 0 && (cfg == 0 || (cfg == 1 && probs[0].K <= 512)) &&
-                              getenv("BVC_GEMM_NO_PERSIST") == nullptr;
+                              BVC_EXP_ENV("BVC_GEMM_NO_PERSIST") == nullptr;
     if (nprob == 1 && (tile_cfg == 6 || tile_cfg == 7 || tile_cfg == 9 || auto_persist)) {
         // deferred stores (gemm_persist.hip) measured on the decoder shapes at B=64 (profiles/r01_f_gemm_ksweep_b64.txt, tile 9 vs 6):
         // GELU' epilogue -8 ... -18 % at K <= 384, -2 % at K = 768; plain bf16 +-0; GELU (two outputs, 253 VGPRs) +8 % slower.
         // So: the GELU' products only.  BVC_GEMM_DEFER=1 / =0 force it on (where possible) / off for A/Bs.
-        const char* dv = getenv("BVC_GEMM_DEFER");
+        const char* dv = BVC_EXP_ENV("BVC_GEMM_DEFER");
         const int defer = tile_cfg == 9 ? 2 : tile_cfg >= 0 ? 0 : dv ? (dv[0] == '1' ? 1 : 0) : (probs[0].epi == EPI_DGELU ? 1 : 0);
         const int rc = launch_gemm_persist(g, layout, cfg, stream, defer);
         if (rc != 1) return rc;

@@ -3,6 +3,7 @@
 // peak - and tools/gemm_ksweep.py measures 816 TFLOP/s marginal (33 % of peak) for the 128x128 kernel.  A 128x64 wave tile
 // needs 1/42.7 B/flop (75 % of the LDS peak at MFMA peak); 32-deep K steps keep two 24 KiB stages = 48 KiB per workgroup so
 // that two workgroups still share a CU.  Reached through bvc_op_gemm(tile_cfg = 3): NT layout, one problem, EPI_BF16 (+ bias).
+#ifdef BVC_EXPERIMENTS     // compiled into the library only for tools/ (see gemm_tile.h)
 #include "gemm.h"
 
 namespace bvc {
@@ -251,3 +252,4 @@ int launch_gemm_big_nt(const GemmProblem& p, int cfg, hipStream_t stream) {
 }
 
 }  // namespace bvc
+#endif  // BVC_EXPERIMENTS

@@ -130,13 +130,13 @@ __global__ __launch_bounds__(256, 2) void gemm_persist_kernel(const GemmGroup g)
                 for (int j = 0; j < TN; ++j) bfr[ks][j] = read_frag<BN, BT>(slot + A_BYTES, wn * WN + 16 * j, ks, lane);
             }
             auto mfma_half = [&](int ks) {
-                if (g.dbg & 64) __builtin_amdgcn_s_setprio(1);      // experiment: raised priority over the MFMA burst
+                if (BVC_DBG(g, 64)) __builtin_amdgcn_s_setprio(1);      // experiment: raised priority over the MFMA burst
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ks][j], af[ks][i], acc[i][j], 0, 0, 0);
-                if (g.dbg & 64) __builtin_amdgcn_s_setprio(0);
+                if (BVC_DBG(g, 64)) __builtin_amdgcn_s_setprio(0);
             };
             mfma_half(0);
             // this slot is refilled with K step it + 2 of the stream: of this tile, or of the next one
@@ -317,7 +317,7 @@ int launch_gemm_persist(const GemmGroup& g, GemmLayout layout, int cfg, hipStrea
     const bool epi_ok = epi == EPI_F32 || epi == EPI_BF16 || epi == EPI_GELU || epi == EPI_RESID || epi == EPI_DGELU || epi == EPI_F32_BF16;
     if (!(layout == GEMM_NT || layout == GEMM_NN) || cfg > 1 || p.split_k != 1 || !epi_ok || p.K % 64 != 0 || p.K < 128 || g.panel[0] <= 0)
         return 1;
-    static const int min_tiles = getenv("BVC_PERSIST_MIN_TILES") ? atoi(getenv("BVC_PERSIST_MIN_TILES")) : 2 * 512;
+    static const int min_tiles = BVC_EXP_ENV("BVC_PERSIST_MIN_TILES") ? atoi(BVC_EXP_ENV("BVC_PERSIST_MIN_TILES")) : 2 * 512;
     if (tiles < min_tiles) return 1;             // fewer than two rounds of the resident workgroups: little to chain
     // deferred stores: 128x128 tiles, epilogues whose outputs are bf16, output below 4 GiB (buffer-descriptor stores)
     const bool defer_ok = cfg == 0 && (epi == EPI_BF16 || epi == EPI_GELU || epi == EPI_DGELU) && (size_t)p.M * p.ldc * 2 < 0xFFFFFFF0ull;

@@ -9,6 +9,18 @@ namespace bvc {
 #define AS3 __attribute__((address_space(3)))
 #endif
 
+// Experiment hooks (BVC_GEMM_DEBUG bits inside the kernels, per-launch environment switches, the 32-deep-K kernels of
+// gemm_big.hip behind tile configs 3-5 / 8) exist only in a -DBVC_EXPERIMENTS build (BVC_EXTRA_HIPCC_FLAGS=-DBVC_EXPERIMENTS,
+// used by tools/gemm_dbg.py, tools/gemm_ksweep.py and the same-process A/Bs of tools/microbench.py); the product library
+// compiles them out.
+#ifdef BVC_EXPERIMENTS
+#define BVC_DBG(g, bits) ((g).dbg & (bits))
+#define BVC_EXP_ENV(name) getenv(name)
+#else
+#define BVC_DBG(g, bits) 0
+#define BVC_EXP_ENV(name) ((const char*)nullptr)
+#endif
+
 struct GemmGroup {
     int nprob;
     int tile_start[kMaxGroup + 1];

@@ -363,6 +363,12 @@ int bvc_predictor_forward(bvc_pred_ctx* c, const float* z, const int* idx_ctx, c
 
 // dout f32 [nsets*B*Np][D] -> grads (flat f32, overwritten) and dz f32 [B*Nc][D] (gradient for the context encoder)
 int bvc_predictor_backward(bvc_pred_ctx* c, const float* dout, float* G, float* dz, void* stream) {
+    return bvc_predictor_backward_cb(c, dout, G, dz, nullptr, nullptr, stream);
+}
+
+// The same with gradient ranges reported tail-first as their kernels are enqueued (bvc_bucket_fn): [norm .. end) after the final
+// LayerNorm's backward, one range per block, [0 .. first block) at the end - what the data-parallel wrapper buckets on.
+int bvc_predictor_backward_cb(bvc_pred_ctx* c, const float* dout, float* G, float* dz, bvc_bucket_fn on_bucket, void* user, void* stream) {
     BVC_REQUIRE(c && dout && G && dz, "predictor_backward: null argument");
     if (!c->have_forward) { set_error("predictor_backward: no forward state"); return BVC_ERR_STATE; }
     c->have_forward = false;
@@ -391,10 +397,11 @@ int bvc_predictor_backward(bvc_pred_ctx* c, const float* dout, float* G, float* 
     const RowMap tail{Np, T, Nc};
     TRY(launch_ln_bwd(c->w.dln, c->st.x_out, tail, c->meanf, c->rstdf, params + L.norm_w, c->dres, 0, c->w.dyb[0],
                       G + L.norm_w, G + L.norm_b, c->w.ln_part, Mo, Dp, st));
+    if (on_bucket) on_bucket(L.norm_w, L.total - L.norm_w, user);
     for (int i = c->st.nlayers - 1; i >= 0; --i)
-        TRY(layer_backward(c->w, c->st, i, L.blocks[i], c->st.act[i].x_in, c->dres, G, S, T, st, nullptr, nullptr));
-    TRY(join_side(c->w, c->w.seq & 1, st, nullptr, nullptr));
-    TRY(join_side(c->w, (c->w.seq + 1) & 1, st, nullptr, nullptr));
+        TRY(layer_backward(c->w, c->st, i, L.blocks[i], c->st.act[i].x_in, c->dres, G, S, T, st, on_bucket, user));
+    TRY(join_side(c->w, c->w.seq & 1, st, on_bucket, user));
+    TRY(join_side(c->w, (c->w.seq + 1) & 1, st, on_bucket, user));
     // sequence assembly: mask token (summed over every predicted position), context tokens (summed over the nsets copies)
     TRY(launch_colsum_f32(c->dres, tail, Mo, Dp, G + L.mask_token, st));
     TRY(launch_pred_ctx_grad(c->dres, c->dxe, nsets, B, Nc, Np, Dp, st));
@@ -408,6 +415,7 @@ int bvc_predictor_backward(bvc_pred_ctx* c, const float* dout, float* G, float* 
         GemmProblem p = gemm(c->dxe, (size_t)Mc * Dp, Dp, W + L.emb_w, (size_t)Dp * D, D, Mc, D, Dp, EPI_F32, dz, D);
         TRY(launch_gemm(&p, 1, GEMM_NN, -1, st));
     }
+    if (on_bucket) on_bucket(0, L.blocks.front().ln1w, user);      // mask token, (frozen) positions, predictor_embed
     return BVC_OK;
 }
 

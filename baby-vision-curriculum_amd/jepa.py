@@ -292,10 +292,9 @@ class VisionTransformerPredictor(FlatParamModule):
         target, accumulate = self._grad_target()
         d = dout.detach().to(torch.float32).contiguous()
         dz = torch.empty_like(zf)
-        _lib.check(_lib.lib().bvc_predictor_backward(self._ctx, d.data_ptr(), target.data_ptr(), dz.data_ptr(),
-                                                     _lib.current_stream_ptr()), "bvc_predictor_backward")
-        if self._bucket_hook is not None and not accumulate:
-            self._bucket_hook(0, self._numel)
+        cb = self._bucket_callback(accumulate)      # per-block gradient ranges, tail first, for the data-parallel wrapper
+        _lib.check(_lib.lib().bvc_predictor_backward_cb(self._ctx, d.data_ptr(), target.data_ptr(), dz.data_ptr(), cb, None,
+                                                        _lib.current_stream_ptr()), "bvc_predictor_backward")
         self._publish_grads(target, accumulate)
         self._live = None
         return dz

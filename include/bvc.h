@@ -175,6 +175,10 @@ void bvc_predictor_destroy(bvc_pred_ctx* ctx);
 int bvc_predictor_forward(bvc_pred_ctx* ctx, const float* z_dev, const int* idx_ctx_dev, const int* idx_pred_dev, int B, int Nc,
                           int nsets, int Np, const float* params_dev, float* out_dev, void* stream);
 int bvc_predictor_backward(bvc_pred_ctx* ctx, const float* dout_dev, float* grads_dev, float* dz_dev, void* stream);
+/* The same, reporting gradient ranges tail-first (bvc_bucket_fn, as bvc_videomae_backward / bvc_vit_backward do) so that the
+ * data-parallel wrapper can start the predictor's all-reduce per block: DDP(predictor, static_graph=True), pretrain_jepa.py:303. */
+int bvc_predictor_backward_cb(bvc_pred_ctx* ctx, const float* dout_dev, float* grads_dev, float* dz_dev, bvc_bucket_fn on_bucket,
+                              void* user, void* stream);
 
 /* forward_target's post-processing (pretrain_jepa.py:387-392): F.layer_norm without affine over the feature dim, then the
  * rows the prediction masks select: out[(i*B+b)*Np + j] = LN(h[b*L + idx_pred[i][b][j]]) */
@@ -214,7 +218,9 @@ typedef struct bvc_gemm_desc {
     int rin, rout;
     float* rowsum;                  /* TN only: rowsum[m] += alpha * sum_k A(m,k)  (bias gradient of the same dY) */
 } bvc_gemm_desc;
-/* tile_cfg: -1 auto, 0 = 128x128, 1 = 128x64, 2 = 64x64;  stages: -1 auto, 2..4 = LDS ring depth */
+/* tile_cfg: -1 auto; 0 = 128x128, 1 = 128x64, 2 = 64x64 (one workgroup per tile); 6 / 7 = persistent 128x128 / 128x64,
+ * 9 = persistent 128x128 with deferred stores; 10 / 11 = 256x256 / 256x128, one 512-thread workgroup per CU (gemm8.hip).
+ * (3-5 and 8 are experiment kernels that exist only in a -DBVC_EXPERIMENTS build.)  stages: -1 auto, 2..4 = K-loop variant. */
 int bvc_op_gemm(const bvc_gemm_desc* problems, int count, int layout, int tile_cfg, int stages, void* stream);
 int bvc_op_gemm_num_tiles(const bvc_gemm_desc* problem, int tile_cfg);
 

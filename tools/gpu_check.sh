@@ -1,5 +1,6 @@
 #!/bin/bash
 # Run on the GPU box (via gpurun): per-kernel parity, whole-step parity, bench, rocprof.
+# Steps micro / gemmdbg / ksweep / racescreen / dwsweep / probe need `exp` first (a -DBVC_EXPERIMENTS build); `noexp` switches back.
 # A step that is killed by its timeout stops the chain (no further GPU work after a hang).
 R=$PWD
 OUT=$R/gpurun_out
@@ -21,6 +22,10 @@ rocminfo | grep -E "Marketing Name|Compute Unit|Max Clock" | tail -3 >> $OUT/sum
 nproc >> $OUT/summary.txt
 for step in "$@"; do
   case $step in
+    # the same-process A/B tools flip per-launch environment switches that exist only in an experiments build of the library
+    exp)   export BVC_EXTRA_HIPCC_FLAGS=-DBVC_EXPERIMENTS; run expbuild 400 python -c "import __graft_entry__ as g; g.build()" ;;
+    noexp) unset BVC_EXTRA_HIPCC_FLAGS; run prodbuild 400 python -c "import __graft_entry__ as g; g.build()" ;;
+    g8ab)  run g8ab 500 python tools/gemm8_ab.py ;;
     ops)   run ops 420 python -m pytest tests/test_gpu_ops.py -m gpu -q -p no:cacheprovider ;;
     model) run model 420 python -m pytest tests/test_gpu_videomae.py -m gpu -q -p no:cacheprovider ;;
     all)   run alltests 600 python -m pytest tests -m gpu -q -x -p no:cacheprovider ;;

@@ -6,7 +6,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libbvc_hip.so")
+# BVC_LIB_PATH: another build of the same library (tools/: A/B of two builds on one box); the default is the in-tree build
+LIB_PATH = os.environ.get("BVC_LIB_PATH") or os.path.join(_HERE, "libbvc_hip.so")
 
 c_void_p, c_int, c_int64, c_float, c_char_p = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_char_p
 c_double = ctypes.c_double

@@ -204,6 +204,13 @@ int bvc_videomae_create(const bvc_videomae_config* cfg, int max_batch, int num_m
     A(c->arena.alloc(&c->wbf, (size_t)c->lay.total));
     A(c->arena.alloc(&c->vis_idx, Mv));
     A(c->arena.alloc(&c->msk_idx, Mm));
+    // token 0 everywhere: a clip whose mask count differs from the context's leaves entries unwritten, and the gather kernels
+    // must then read in-range indices (the status word flags the clip; the Python side raises on the next step)
+    if (hipMemset(c->vis_idx, 0, (size_t)Mv * sizeof(int)) != hipSuccess || hipMemset(c->msk_idx, 0, (size_t)Mm * sizeof(int)) != hipSuccess) {
+        set_error("videomae_create: hipMemset of the token lists failed");
+        bvc_videomae_destroy(c);
+        return BVC_ERR_HIP;
+    }
     A(c->arena.alloc(&c->status, 4));
     A(c->arena.alloc(&c->Ape, Mv * c->Kp));
     A(alloc_stack(c->arena, c->enc, D, I, H, cfg->num_hidden_layers, cfg->layer_norm_eps, Mv, B * H * c->nvis));

@@ -40,6 +40,20 @@ class FlatParamModule(nn.Module):
         self._flat_grad = None
         self._bucket_hook = None      # set by the data-parallel wrapper: fn(offset, count)
         self._after_backward = None
+        self._fwd_generation = 0      # bumped by every forward that overwrites the library context's saved activations
+
+    def _stamp_forward(self):
+        """The library context keeps ONE set of saved activations: every forward stamps it; backward checks the stamp."""
+        self._fwd_generation = getattr(self, "_fwd_generation", 0) + 1
+        return (self._fwd_generation, getattr(self, "_ctx", None))
+
+    def _check_generation(self, stamp):
+        gen, ctx = stamp
+        cur = getattr(self, "_ctx", None)
+        same_ctx = (ctx is cur) or (ctx is not None and cur is not None and getattr(ctx, "value", ctx) == getattr(cur, "value", cur))
+        if gen != getattr(self, "_fwd_generation", 0) or not same_ctx:
+            raise _lib.BvcError("backward of a forward whose saved activations were overwritten: this module ran another forward "
+                                "(validation pass, second view, larger batch) between that forward and its backward")
 
     def _register(self, dotted, param):
         mod = self

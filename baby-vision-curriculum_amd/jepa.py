@@ -99,10 +99,13 @@ class _EncFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, anchor, model, imgs, idx):
         ctx.model = model
-        return model._run_forward(imgs, idx)
+        out = model._run_forward(imgs, idx)
+        ctx.stamp = model._stamp_forward()
+        return out
 
     @staticmethod
     def backward(ctx, dout):
+        ctx.model._check_generation(ctx.stamp)
         ctx.model._run_backward(dout)
         return None, None, None, None
 
@@ -205,7 +208,9 @@ class VisionTransformer(FlatParamModule):
         anchor = self._param("norm.weight")
         if torch.is_grad_enabled() and anchor.requires_grad:
             return _EncFn.apply(anchor, self, imgs, idx)
-        return self._run_forward(imgs, idx)
+        out = self._run_forward(imgs, idx)
+        self._stamp_forward()         # a pending backward of an earlier forward must not run on these activations
+        return out
 
 
 # ----------------------------------------------------------------------------- predictor
@@ -214,10 +219,13 @@ class _PredFn(torch.autograd.Function):
     def forward(ctx, z, model, idx_ctx, idx_pred, anchor):
         ctx.model = model
         ctx.z_dtype = z.dtype
-        return model._run_forward(z, idx_ctx, idx_pred)
+        out = model._run_forward(z, idx_ctx, idx_pred)
+        ctx.stamp = model._stamp_forward()
+        return out
 
     @staticmethod
     def backward(ctx, dout):
+        ctx.model._check_generation(ctx.stamp)
         dz = ctx.model._run_backward(dout)
         return dz.to(ctx.z_dtype), None, None, None, None
 
@@ -317,7 +325,9 @@ class VisionTransformerPredictor(FlatParamModule):
         anchor = self._param("predictor_norm.weight")
         if torch.is_grad_enabled() and (x.requires_grad or anchor.requires_grad):
             return _PredFn.apply(x, self, idx_ctx, idx_pred, anchor)
-        return self._run_forward(x, idx_ctx, idx_pred)
+        out = self._run_forward(x, idx_ctx, idx_pred)
+        self._stamp_forward()
+        return out
 
 
 # ----------------------------------------------------------------------------- factories (vision_transformer.py:538-590)

@@ -107,9 +107,10 @@ class SGD(torch.optim.Optimizer):
         return loss
 
     def state_dict(self):
+        # shallow copies: super().state_dict() hands out the LIVE per-parameter dicts, popping from them would drop the flat
+        # state of the running optimiser (reallocation + host sync on the next step)
         sd = super().state_dict()
-        for st in sd["state"].values():
-            st.pop("_flat_momentum", None)
+        sd["state"] = {k: {n: v for n, v in st.items() if not n.startswith("_flat_")} for k, st in sd["state"].items()}
         return sd
 
 
@@ -182,9 +183,10 @@ class Adam(torch.optim.Optimizer):
         return loss
 
     def state_dict(self):
+        # shallow copies: super().state_dict() hands out the LIVE per-parameter dicts, popping from them would drop the flat
+        # state of the running optimiser (reallocation + host sync on the next step)
         sd = super().state_dict()
-        for st in sd["state"].values():
-            st.pop("_flat_adam", None)
+        sd["state"] = {k: {n: v for n, v in st.items() if not n.startswith("_flat_")} for k, st in sd["state"].items()}
         return sd
 
 

@@ -83,11 +83,13 @@ class _Step(torch.autograd.Function):
     def forward(ctx, anchor, model, pixels, mask, want_logits):
         ctx.model = model
         loss, logits = model._run_forward(pixels, mask, want_logits)
+        ctx.stamp = model._stamp_forward()
         ctx.mark_non_differentiable(logits) if logits is not None else None
         return loss, logits
 
     @staticmethod
     def backward(ctx, grad_loss, _grad_logits):
+        ctx.model._check_generation(ctx.stamp)
         ctx.model._run_backward(grad_loss)
         return None, None, None, None, None
 
@@ -144,14 +146,36 @@ class VideoMAEForPreTraining(FlatParamModule):
 
     # ---- step
     def _num_masked(self, mask):
+        """Masked tokens per clip.  One host sync on the first call per mask shape; afterwards the cached count is VERIFIED
+        asynchronously: every call leaves `count(row 0) != cached` and `rows differ` flags in a pinned word that the next call
+        reads (a ratio change at the same shape - a validation phase, a curriculum stage - raises on the following step
+        instead of training on NaN losses that GradScaler silently skips)."""
         key = tuple(mask.shape)
+        pend = getattr(self, "_nmask_pending", None)
+        if pend is not None:
+            ev, flag, pkey = pend
+            ev.synchronize()                    # the previous step's check: long done, no stall
+            self._nmask_pending = None
+            if int(flag[0]) != 0:
+                self._nmask_cache.pop(pkey, None)
+                raise ValueError("bool_masked_pos: the number of masked patches per clip changed (or differs between clips) "
+                                 "without a new model object; every clip must mask the same number of patches")
         if self.strict_mask_check or key not in self._nmask_cache:
             counts = mask.sum(dim=1)
             n = int(counts[0])       # one host sync, first call per shape only
-            if self.strict_mask_check and not bool((counts == n).all()):
+            if not bool((counts == n).all()):
                 raise ValueError("every clip must have the same number of masked patches")
             self._nmask_cache[key] = n
-        return self._nmask_cache[key]
+            return n
+        n = self._nmask_cache[key]
+        if not hasattr(self, "_nmask_flag"):
+            self._nmask_flag = torch.zeros(1, dtype=torch.int32).pin_memory()
+        bad = (mask.sum(dim=1) != n).any().to(torch.int32).reshape(1)
+        self._nmask_flag.copy_(bad, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(mask.device))
+        self._nmask_pending = (ev, self._nmask_flag, key)
+        return n
 
     def _run_forward(self, pixels, mask, want_logits):
         cfg = self.config
@@ -201,6 +225,7 @@ class VideoMAEForPreTraining(FlatParamModule):
             loss, logits = _Step.apply(anchor, self, pixels, mask, output_logits)
         else:
             loss, logits = self._run_forward(pixels, mask, output_logits)
+            self._stamp_forward()     # a pending backward of an earlier forward must not run on these activations
         return VideoMAEForPreTrainingOutput(loss=loss, logits=logits)
 
     # ---- parity probes

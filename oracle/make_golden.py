@@ -167,12 +167,30 @@ def simclr_fixture():
         cases.append({"B": B, "p": p, "seed": seed, "temperature": 0.1, "n_pos": int(masks[0].sum()), "n_neg": int(masks[1].sum()),
                       "loss": float(loss), "grad_l2": float(feats.grad.double().norm()),
                       "grad_head": [float(x) for x in feats.grad.flatten()[:6]]})
+    # BASELINE config sizes.  B = 256 / p = 2048 (512 rows) still fits the reference function's (n, n, p) broadcast product
+    # (2.1 GB); 4096 pairs (8192 rows) would need 550 GB, so that case is produced by the oracle's low-memory form, which is
+    # first checked here against the reference function at 512 rows.
+    for B, p, seed, use_ref in [(256, 2048, 5, True), (4096, 2048, 6, False)]:
+        feats = so.synthetic_features(2 * B, p, seed).requires_grad_(True)
+        if use_ref:
+            loss = ref.info_nce_loss(0.1, so.make_masks(B), feats)
+            low = so.info_nce_loss_lowmem(0.1, B, feats.detach())
+            assert abs(float(low) - float(loss)) < 2e-6 * abs(float(loss)), (float(low), float(loss))
+        else:
+            loss = so.info_nce_loss_lowmem(0.1, B, feats)
+        loss.backward()
+        cases.append({"B": B, "p": p, "seed": seed, "temperature": 0.1, "n_pos": 2 * (2 * B - 1), "n_neg": 4 * B * B - 2 * B - 2 * (2 * B - 1),
+                      "loss": float(loss), "grad_l2": float(feats.grad.double().norm()),
+                      "grad_head": [float(x) for x in feats.grad.flatten()[:6]],
+                      "produced_by": "reference info_nce_loss" if use_ref else
+                                     "oracle info_nce_loss_lowmem (the reference function's broadcast product needs 550 GB at this size)"})
+        print(f"[simclr] B={B} p={p}: loss {float(loss):.6f} ({cases[-1]['produced_by']})")
     with open(os.path.join(GOLD, "simclr_info_nce.json"), "w") as f:
         json.dump({"source": "pretraining/contrastive/pretrain_simclr.py:86-91,114-128,284-292", "cases": cases}, f, indent=1)
     print("[simclr] reference info_nce_loss == oracle for", len(cases), "cases; B=8:", cases[0]["n_pos"], "pos /", cases[0]["n_neg"], "neg")
 
 
-def jepa_fixture():
+def jepa_fixture(large=False):
     """pretraining/predictive/{vision_transformer,tensors,mask}.py (need only torch/numpy): the reference's own encoder,
     predictor and train-step arithmetic with the oracle's deterministic weights, and its MaskCollator under fixed seeds."""
     import torch.nn.functional as F
@@ -185,8 +203,11 @@ def jepa_fixture():
     import mask as rmask
     from functools import partial
     cases = []
-    for name, cfg, B, n_ctx, n_pred, seed in [("tiny", jo.TINY, 3, 6, 4, 0), ("tiny_b", jo.TINY, 2, 9, 5, 1), ("vit_b", jo.VIT_B, 2, 83, 25, 0),
-                                                ("tiny_hd24", jo.TINY_HD24, 2, 7, 5, 2)]:
+    specs = [("tiny", jo.TINY, 3, 6, 4, 0), ("tiny_b", jo.TINY, 2, 9, 5, 1), ("vit_b", jo.VIT_B, 2, 83, 25, 0),
+             ("tiny_hd24", jo.TINY_HD24, 2, 7, 5, 2)]
+    if large:      # BASELINE config 4: ViT-L/16 (1024 wide, 24 layers, 16 heads; predictor heads of 24 dims), N_ctx 100, N_pred 25
+        specs = [("vit_l", jo.VIT_L, 2, 100, 25, 0)]
+    for name, cfg, B, n_ctx, n_pred, seed in specs:
         enc_p = jo.make_params(jo.encoder_shapes(cfg), cfg, seed)
         pred_p = jo.make_params(jo.predictor_shapes(cfg), cfg, seed + 50)
         tgt_p = jo.make_params(jo.encoder_shapes(cfg), cfg, seed + 100)
@@ -231,6 +252,11 @@ def jepa_fixture():
                       "grad_first_qkv": float(gn[first_qkv].grad.double().norm()), "grad_last_qkv": float(gn[last_qkv].grad.double().norm()),
                       "enc_grad_l2": {k: float(p.grad.double().norm()) for k, p in enc.named_parameters() if p.grad is not None},
                       "pred_grad_l2": {k: float(p.grad.double().norm()) for k, p in pred.named_parameters() if p.grad is not None}})
+    if large:
+        with open(os.path.join(GOLD, "jepa_vit_l.json"), "w") as f:
+            json.dump({"source": "pretraining/predictive/vision_transformer.py:572-576 (vit_large), tensors.py, pretrain_jepa.py:383-402",
+                       "cases": cases}, f, indent=1)
+        return
     # MaskCollator: block sizes are seeded by the step counter, positions by the global torch RNG
     mc_cases = []
     for gseed in (0, 5):
@@ -290,6 +316,11 @@ def embedding_fixture():
 def main():
     os.makedirs(GOLD, exist_ok=True)
     torch.manual_seed(0)
+    if "--full-size" in sys.argv:      # the BASELINE-size pins only (minutes of CPU): VideoMAE-base B=16, JEPA ViT-L, SimCLR 512 / 8192 rows
+        one_case("base_b16_s0", vo.BASE, batch=16, seed=0, mask_ratio=0.9)
+        jepa_fixture(large=True)
+        simclr_fixture()
+        return
     mask_fixture()
     simclr_fixture()
     jepa_fixture()
@@ -300,6 +331,8 @@ def main():
     one_case("tiny_s1", vo.TINY, batch=3, seed=1, mask_ratio=0.75, wseed=1)
     one_case("base_b2_s0", vo.BASE, batch=2, seed=0, mask_ratio=0.9)
     one_case("base_b2_s1", vo.BASE, batch=2, seed=1, mask_ratio=0.9, wseed=1)
+    one_case("base_b16_s0", vo.BASE, batch=16, seed=0, mask_ratio=0.9)
+    jepa_fixture(large=True)
 
 
 if __name__ == "__main__":

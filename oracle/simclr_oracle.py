@@ -35,6 +35,30 @@ def info_nce_loss(temperature, masks, feats):
     return (neg_part + pos_part).mean()
 
 
+def info_nce_loss_lowmem(temperature, batch_size, feats, eps=1e-8):
+    """The same loss without the (n, n, p) broadcast product of F.cosine_similarity (550 GB at 8192 rows x 2048): rows
+    normalised as cosine_similarity does (each norm clamped at eps), one (n, n) product, the reference's masks applied by
+    index arithmetic.  Checked against info_nce_loss (and through it against the reference's function) up to 512 rows by
+    oracle/make_golden.py and tests/test_simclr_oracle.py."""
+    n = 2 * batch_size
+    fn = feats / feats.norm(dim=1, keepdim=True).clamp_min(eps)
+    cos = fn @ fn.t() / temperature
+    i = torch.arange(n)
+    d = (i[:, None] - i[None, :]).abs()
+    pos = cos[d == 1]
+    neg = cos[d > 1]
+    return torch.logsumexp(neg, dim=-1) - pos.mean()
+
+
+def head_forward_bf16_operands(x, w1, b1, w2, b2):
+    """head_forward with every GEMM operand rounded to bf16 (x, both weights, the hidden activation) and f32 accumulation: what
+    a bf16-MFMA implementation computes up to summation order.  The ReLU gates are then decided by the same numbers the
+    device sees, which separates operand rounding from gate flips in the gradient comparison (tests/test_gpu_simclr.py)."""
+    r = lambda t: t.to(torch.bfloat16).to(torch.float32)   # noqa: E731
+    h = F.relu(F.linear(r(x), r(w1), b1))
+    return F.linear(r(h), r(w2), b2)
+
+
 def head_forward(x, w1, b1, w2, b2):
     return F.linear(F.relu(F.linear(x, w1, b1)), w2, b2)
 

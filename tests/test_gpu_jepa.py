@@ -35,9 +35,13 @@ def _modules(cfg, enc_p, pred_p, tgt_p):
     return enc.to(dev), pred.to(dev), tgt.to(dev)
 
 
-@pytest.mark.parametrize("idx", [0, 1, 2, 3])     # 3 = predictor heads of 24 dims (ViT-L's shape), run zero-padded to 32
+# 3 = predictor heads of 24 dims (ViT-L's shape) at toy size, run zero-padded to 32; 4 = BASELINE config 4 itself: ViT-L/16
+# (1024 wide, 24 layers, 16 heads, predictor heads of 24 dims), B=2, N_ctx 100, N_pred 25 (tests/golden/jepa_vit_l.json)
+@pytest.mark.parametrize("idx", [0, 1, 2, 3, 4])
 def test_train_step_matches_oracle_and_fixture(golden_dir, idx):
-    c = json.load(open(os.path.join(golden_dir, "jepa.json")))["cases"][idx]
+    cases = json.load(open(os.path.join(golden_dir, "jepa.json")))["cases"] + \
+        json.load(open(os.path.join(golden_dir, "jepa_vit_l.json")))["cases"]
+    c = cases[idx]
     cfg = jo.JepaConfig(**c["config"])
     enc_p = jo.make_params(jo.encoder_shapes(cfg), cfg, c["seed"])
     pred_p = jo.make_params(jo.predictor_shapes(cfg), cfg, c["seed"] + 50)

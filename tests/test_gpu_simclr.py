@@ -18,11 +18,13 @@ bvc = G.bvc
 dev = torch.device("cuda:0")
 
 
-@pytest.mark.parametrize("B,p,seed", [(8, 128, 0), (32, 512, 1), (4, 64, 2), (256, 128, 3), (1024, 256, 4)])
+# (256, 2048, 5) = the reference's width at 512 rows; (4096, 2048, 6) = BASELINE config 5's global batch: 8192 rows x 2048
+@pytest.mark.parametrize("B,p,seed", [(8, 128, 0), (32, 512, 1), (4, 64, 2), (256, 128, 3), (1024, 256, 4), (256, 2048, 5), (4096, 2048, 6)])
 def test_info_nce_loss_and_gradient(golden_dir, B, p, seed):
     feats = so.synthetic_features(2 * B, p, seed)
     ref_in = feats.clone().requires_grad_(True)
-    ref = so.info_nce_loss(0.1, so.make_masks(B), ref_in)
+    # the (n, n, p) broadcast product of the reference formulation needs 550 GB at 8192 rows: there the oracle's (n, n) form
+    ref = so.info_nce_loss(0.1, so.make_masks(B), ref_in) if B <= 1024 else so.info_nce_loss_lowmem(0.1, B, ref_in)
     (ref * 3.0).backward()
     x = feats.to(dev).requires_grad_(True)
     masks = bvc.simclr.make_masks(B, dev)
@@ -64,12 +66,28 @@ def test_projection_head_forward_backward(n, pin, pout):
     out.backward(dout.to(dev))
     torch.cuda.synchronize()
     assert G.rel_err(out.cpu(), ro.detach()) < 1e-2
-    # Gradients pass through a ReLU whose pre-activations carry bf16 operand noise (~1e-3 sigma): the ~0.1 % of units
-    # within that distance of zero flip their gate, and dropping/adding whole terms gives a relative L2 error of
-    # sqrt(fraction flipped) ~ 3-4 % - inherent to bf16 operands (the reference's autocast path has it too), so 8e-2.
-    assert G.rel_err(x.grad.cpu(), rx.grad) < 8e-2
+    # Gradients pass through a ReLU whose pre-activations carry bf16 operand noise: units within that distance of zero flip
+    # their gate against the f32 oracle, and dropping / adding whole terms costs a relative L2 error of ~sqrt(fraction
+    # flipped).  MEASURED here instead of asserted: the same head with every GEMM operand rounded to bf16 on the CPU
+    # (so.head_forward_bf16_operands) decides its gates on the numbers the device sees - against it the gradients agree to
+    # 1.5e-2 (operand rounding only), and the fraction of gates that differ from the f32 oracle explains the rest.
+    bp = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    bx = x0.clone().requires_grad_(True)
+    bo = so.head_forward_bf16_operands(bx, bp["0.weight"], bp["0.bias"], bp["2.weight"], bp["2.bias"])
+    bo.backward(dout)
+    pre32 = torch.nn.functional.linear(x0, params["0.weight"], params["0.bias"])
+    r = lambda t: t.to(torch.bfloat16).float()   # noqa: E731
+    pre16 = torch.nn.functional.linear(r(x0), r(params["0.weight"]), params["0.bias"])
+    flipped = float(((pre32 > 0) != (pre16 > 0)).float().mean())
+    e32, e16 = G.rel_err(x.grad.cpu(), rx.grad), G.rel_err(x.grad.cpu(), bx.grad)
+    print(f"head {n}x{pin}->{pout}: gates flipped vs f32 oracle {flipped:.2e} (sqrt {flipped ** 0.5:.2e}); dX rel err vs f32 oracle {e32:.2e}, "
+          f"vs bf16-operand oracle {e16:.2e}")
+    assert e16 < 1.5e-2, e16
+    assert e32 < max(2e-2, 3.0 * flipped ** 0.5), (e32, flipped)      # what the flipped gates allow, not a blanket 8e-2
     for k in params:
-        assert G.rel_err(dict(head.named_parameters())[k].grad.cpu(), rp[k].grad) < 8e-2, k
+        g = dict(head.named_parameters())[k].grad.cpu()
+        assert G.rel_err(g, bp[k].grad) < 1.5e-2, k
+        assert G.rel_err(g, rp[k].grad) < max(2e-2, 3.0 * flipped ** 0.5), k
 
 
 def test_simclr_step_like_the_reference_loop():

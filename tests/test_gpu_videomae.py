@@ -118,6 +118,42 @@ def test_base_step_matches_oracle_and_fixture(golden_dir, case):
     _check_step(case, vo.BASE, fx["batch"], fx["seed"], fx["mask_ratio"], wseed=fx["weight_seed"], fixture=fx)
 
 
+def test_base_b16_matches_transformers_fixture(golden_dir):
+    """The reference's own per-GPU batch (slurm_dev_def.bash:52): VideoMAE-base, 16 clips, against the numbers transformers 5.15.0
+    produced in the build container (tests/golden/videomae_base_b16_s0.json): loss, the three grad_logger probes (1e-3, the
+    north_star bar) and the L2 norm of every one of the 264 gradient tensors (2e-2; norms only - the fixture holds no tensors)."""
+    with open(os.path.join(golden_dir, "videomae_base_b16_s0.json")) as f:
+        fx = json.load(f)
+    cfg = vo.BASE
+    params = vo.make_params(cfg, seed=fx["weight_seed"])
+    pixels, mask = vo.synthetic_batch(cfg, fx["batch"], fx["seed"], fx["mask_ratio"])
+    assert int(mask.sum()) == fx["input"]["mask_true"]
+    model = _model(cfg, params)
+    out = model(pixels.to(dev), bool_masked_pos=mask.to(dev))
+    out.loss.backward()
+    torch.cuda.synchronize()
+    loss = float(out.loss)
+    rel = abs(loss - fx["loss"]) / fx["loss"]
+    _log(f"[base_b16_s0] loss hip {loss:.7f} transformers {fx['loss']:.7f} rel {rel:.2e}")
+    assert rel < 1e-3
+    named = dict(model.named_parameters())
+    for k in vo.GRAD_PROBES:
+        gn, rn = float(named[k].grad.norm()), fx["grad_probes"][k]
+        e = abs(gn - rn) / rn
+        _log(f"[base_b16_s0] grad-norm {k}: hip {gn:.6e} transformers {rn:.6e} rel {e:.2e} (bar 1e-3, margin {1e-3 / max(e, 1e-12):.1f}x)")
+        assert e < 1e-3, (k, e)
+    gmax = max(fx["grad_l2"].values())
+    worst = ("", 0.0)
+    assert set(fx["grad_l2"]) == set(named)
+    for k, rn in fx["grad_l2"].items():
+        gn = float(named[k].grad.double().norm())
+        e = abs(gn - rn) / (rn + 1e-3 * gmax)
+        if e > worst[1]:
+            worst = (k, e)
+        assert e < 2e-2, (k, gn, rn)
+    _log(f"[base_b16_s0] worst per-tensor gradient-norm rel {worst[1]:.2e} ({worst[0]}) over {len(named)} tensors")
+
+
 @pytest.mark.parametrize("nb", [16, 64])
 def test_full_batch_properties(nb):
     """BASELINE batches (16 clips = the reference's slurm default, 64 = bench.py's default): size-independent properties

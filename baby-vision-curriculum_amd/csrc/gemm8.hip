@@ -41,6 +41,20 @@ struct Unit {
     int pi, m0, n0, kt0, nkt, split, tile;
 };
 
+// Transposed-operand fragment out of a [64 k][128] LDS image (layout and swizzle of gemm_tile.h read_frag<128, true>), with the
+// address arithmetic spelled out so that it costs two vector instructions per fragment instead of one live address register
+// per (row tile, LDS slot): byte address = region + 8192 ks + lane_base + ((32 row_tile) ^ lane_swz), second half 1024 further.
+//   lane_base = (8 (l >> 4) + ((l >> 2) & 3)) * 256 + ((l & 3) >> 1) * 16 + (l & 1) * 8,   lane_swz = swz_tr<128>(k) << 4
+// (the swizzle only touches address bits 5-7, exactly the bits 32 * row_tile occupies).  The kernel passes lane_swz through an
+// empty asm once per phase: hipcc then recomputes the addresses per phase instead of hoisting ~24 of them out of the K loop,
+// which is what pushed the 256 x 256 weight-gradient instantiation over 256 registers.
+__device__ __forceinline__ bf16x8 tr_frag(uint32_t region, uint32_t lane_base, uint32_t lane_swz, uint32_t chunk16, int ks) {
+    const uint32_t a = region + lane_base + (chunk16 ^ lane_swz) + (uint32_t)ks * 8192u;
+    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((AS3 bf16x4*)(size_t)a);
+    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((AS3 bf16x4*)(size_t)(a + 1024u));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
 // unit id -> problem, tile, K range.  Uniform (kernel arguments and blockIdx only).
 template <int BN>
 __device__ __forceinline__ void decode_unit(const GemmGroup& g, int uid, Unit& u) {
@@ -90,7 +104,23 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const GemmGroup g, const 
     constexpr int NB = BN / 64, NBH = BN / 128;
     constexpr int n0c = AT ? NBH : (NB < 2 ? NB : 2), n1c = AT ? 2 : NB - n0c, n2c = AT ? NBH : 2, n3c = 2;
     constexpr int PT = n0c + n1c + n2c + n3c;          // LDS-DMA instructions per wave per K tile
-    constexpr int W1 = PT, W3 = AT ? PT : n3c + n0c + n1c;
+    // Where a phase issues its group.  EARLY (default): in the read segment, after the fragment reads and before the counted wait -
+    // the wave stalls on the LDS-DMA issue (100-185 cycles per instruction there) while the OTHER wave row of its SIMD issues
+    // MFMAs.  LATE (-DBVC_G8_DMA_LATE, kept as a measured alternative): between the MFMAs of the phase; a wave issues in order, so
+    // its MFMAs queue behind the stalled DMA issue - same-box A/B (profiles/r02_c_gemm8_dma_placement_ab.txt): 3-9 % slower on
+    // every product.  The counted waits sit in the read segments of phases 1 and 3 either way; what is younger than the group
+    // they retire differs.
+#ifdef BVC_G8_DMA_LATE
+    constexpr bool LATE = true;
+#else
+    constexpr bool LATE = false;
+#endif
+    constexpr int CPR = WN / 8;                   // epilogue geometry: 8-column chunks per wave-tile row
+    constexpr int NSIDE = TM * (16 / (64 / CPR));  // 16-byte chunks (= bf16 store instructions per output) per lane and unit
+    static_assert(PT + 2 * NSIDE < 64, "vmcnt is a 6-bit counter");
+    constexpr int WP = AT ? PT : n3c + n0c + n1c;                                        // prologue: K tile 0's phase-0 operands
+    constexpr int W1 = LATE ? n0c + n1c + n2c : PT;
+    constexpr int W3 = LATE ? (AT ? n2c + n3c + n0c : n3c + n0c) : WP;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -158,7 +188,13 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const GemmGroup g, const 
     };
     // piece j of an operand tile -> its 8 KiB of LDS at region + j * 8192, this wave's 1 KiB at + wave * 1024
     //   k-contiguous operand: rows 64 j .. 64 j + 63;   transposed operand: half h = j >> 1 (128 columns), k rows 32 (j & 1) ..
-    const uint32_t lds0 = (uint32_t)(size_t)((AS3 char*)smem) + (uint32_t)wave * 1024u;   // this wave's 1 KiB of piece 0 of slot 0
+    const uint32_t lds_base = (uint32_t)(size_t)((AS3 char*)smem);
+    const uint32_t lds0 = lds_base + (uint32_t)wave * 1024u;   // this wave's 1 KiB of piece 0 of slot 0
+    // lane constants of the transposed fragment reads (tr_frag)
+    const uint32_t tr_base = (uint32_t)((8 * (lane >> 4) + ((lane >> 2) & 3)) * 256 + ((lane & 3) >> 1) * 16 + (lane & 1) * 8);
+    const uint32_t tr_swz = (uint32_t)swz_tr<128>(8 * (lane >> 4) + ((lane >> 2) & 3)) << 4;
+    const uint32_t b_region = (uint32_t)(A_BYTES + ((wn * WN) >> 7) * 16384);      // this wave's half of a transposed B tile
+    const uint32_t b_chunk16 = (uint32_t)(2 * ((wn * WN) & 127));                  // its first column, in address bits
     auto load_a = [&](char* region, int j) {
         const uint32_t off = s_la + s_baseA + (AT ? (uint32_t)(j & 1) * s_strideA + (uint32_t)(j >> 1) * 256u : (uint32_t)j * s_strideA);
         glds16(s_ra, off, lds0 + (uint32_t)(region - smem) + (uint32_t)j * 8192u);
@@ -167,59 +203,67 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const GemmGroup g, const 
         const uint32_t off = s_lb + s_baseB + (BT ? (uint32_t)(j & 1) * s_strideB + (uint32_t)(j >> 1) * 256u : (uint32_t)j * s_strideB);
         glds16(s_rb, off, lds0 + (uint32_t)(region - smem) + (uint32_t)j * 8192u);
     };
-    // group GI of the cursor's K tile into LDS slot `buf`; after g3 the cursor moves to the next K tile of the stream
-    auto stage_group = [&](auto gi_, char* buf) {
-        constexpr int GI = decltype(gi_)::value;
-        char* ra_ = buf;
-        char* rb_ = buf + A_BYTES;
-        if constexpr (!AT) {
-            if constexpr (GI == 0) {
-#pragma unroll
-                for (int j = 0; j < n0c; ++j) load_b(rb_, j);
-            } else if constexpr (GI == 1) {
-#pragma unroll
-                for (int j = n0c; j < NB; ++j) load_b(rb_, j);
-            } else if constexpr (GI == 2) {
-                load_a(ra_, 0); load_a(ra_, 2);
-            } else {
-                load_a(ra_, 1); load_a(ra_, 3);
-            }
-        } else {
-            if constexpr (GI == 0) {
-#pragma unroll
-                for (int h = 0; h < NBH; ++h) load_b(rb_, 2 * h);
-            } else if constexpr (GI == 1) {
-                load_a(ra_, 0); load_a(ra_, 2);
-            } else if constexpr (GI == 2) {
-#pragma unroll
-                for (int h = 0; h < NBH; ++h) load_b(rb_, 2 * h + 1);
-            } else {
-                load_a(ra_, 1); load_a(ra_, 3);
-            }
-        }
-        if constexpr (GI == 3) s_advance();
-    };
+    // load K (0 / 1) of group GI of the cursor's K tile into LDS slot `buf`; a group has at most two loads; after the second load
+    // of g3 the cursor moves to the next K tile of the stream
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
     using I2 = std::integral_constant<int, 2>;
     using I3 = std::integral_constant<int, 3>;
+    auto stage_one = [&](auto gi_, auto k_, char* buf) {
+        constexpr int GI = decltype(gi_)::value, K = decltype(k_)::value;
+        char* ra_ = buf;
+        char* rb_ = buf + A_BYTES;
+        if constexpr (!AT) {
+            if constexpr (GI == 0) { if constexpr (K < n0c) load_b(rb_, K); }
+            else if constexpr (GI == 1) { if constexpr (n0c + K < NB) load_b(rb_, n0c + K); }
+            else if constexpr (GI == 2) load_a(ra_, K == 0 ? 0 : 2);
+            else load_a(ra_, K == 0 ? 1 : 3);
+        } else {
+            if constexpr (GI == 0) { if constexpr (K < NBH) load_b(rb_, 2 * K); }
+            else if constexpr (GI == 1) load_a(ra_, K == 0 ? 0 : 2);
+            else if constexpr (GI == 2) { if constexpr (K < NBH) load_b(rb_, 2 * K + 1); }
+            else load_a(ra_, K == 0 ? 1 : 3);
+        }
+        if constexpr (GI == 3 && K == 1) s_advance();
+    };
+    auto stage_group = [&](auto gi_, char* buf) { stage_one(gi_, I0{}, buf); stage_one(gi_, I1{}, buf); };
+    // the group phase q issues: (q + 2) & 3 of the cursor's K tile, into the other slot for q = 0, 1 and into this one for q = 2, 3
+    auto stage_phase = [&](auto q_, auto k_, char* cur, char* oth) {
+        constexpr int Q = decltype(q_)::value;
+        if constexpr (Q == 0) stage_one(I2{}, k_, oth);
+        else if constexpr (Q == 1) stage_one(I3{}, k_, oth);
+        else if constexpr (Q == 2) stage_one(I0{}, k_, cur);
+        else stage_one(I1{}, k_, cur);
+    };
 
     char* const buf0 = smem;
     char* const buf1 = smem + TILE;
     AS3 char* const wl = (AS3 char*)smem + 2 * TILE + wave * (16 * WN * 4);   // wave-private epilogue parking: 16 rows x WN f32
 
+    if constexpr (EC == 0) {
+        // the bias vector of the (single) problem, zero padded to whole tiles, into the LDS the other classes park accumulators
+        // in; read by every unit's epilogue.  Plain loads: hipcc waits for them right here, before any LDS-DMA is in flight.
+        const GemmProblem& p0 = g.prob[0];
+        AS3 float* lbias = (AS3 float*)((AS3 char*)smem + 2 * TILE);
+        const int npad = ((p0.N + BN - 1) / BN) * BN;
+        for (int i = tid; i < npad; i += 512) lbias[i] = (p0.bias && i < p0.N) ? p0.bias[i] : 0.f;
+        __syncthreads();
+    }
     // ------------------------------------------------------------------ prologue: K tile 0 and groups 0, 1 of K tile 1
     s_problem();
     s_ktile();
     stage_group(I0{}, buf0); stage_group(I1{}, buf0); stage_group(I2{}, buf0); stage_group(I3{}, buf0);
     stage_group(I0{}, buf1); stage_group(I1{}, buf1);
-    wait_vmcnt<W3>();
+    wait_vmcnt<WP>();
     asm volatile("s_barrier" ::: "memory");
     if (wm == 1) asm volatile("s_barrier" ::: "memory");     // the stagger: wave row 1 runs one barrier behind wave row 0
 
     Unit cu;
     decode_unit<BN>(g, uid, cu);
-    bool fresh = false;            // first K tile after an epilogue: its operands were drained before the stores
+    // First K tile after an epilogue: what its phase-1 wait has to allow for.  0: the stream ran on, the plain counted wait;
+    // -1: the epilogue drained every load before its stores, no wait needed; n > 0: the epilogue issued n stores BEHIND the
+    // prefetched loads without draining them (vmcnt is one in-order counter), so the wait counts them as younger operations.
+    int after_epi = 0;
 
     bf16x8 ones;
 #pragma unroll
@@ -236,20 +280,24 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const GemmGroup g, const 
         const bool do_rowsum = EC == 2 && p.rowsum != nullptr && cu.n0 == 0;   // bias gradient: wave wn takes row tiles wn and 4 + wn
 
         // one K tile out of LDS slot `cur`; `oth` is the other slot
-        auto ktile = [&](char* cur, char* oth) {
+        auto ktile = [&](auto rs_, char* cur, char* oth) {
+            constexpr bool RS = decltype(rs_)::value;       // with the fused bias-gradient MFMA (its own copy of the K loop: a
+                                                            // branch inside the MFMA cluster cost ~48 live registers)
             const char* la = cur;
             const char* lb = cur + A_BYTES;
             if constexpr (!AT) {
                 bf16x8 bfr[2][TN];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
+                auto phase = [&](auto q_) {
+                    constexpr int q = decltype(q_)::value;
                     __builtin_amdgcn_sched_barrier(0);
-                    if (q == 0) {
+                    uint32_t sw = tr_swz;
+                    if constexpr (BT && q == 0) asm volatile("" : "+v"(sw));
+                    if constexpr (q == 0) {
 #pragma unroll
                         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
                             for (int j = 0; j < TN; ++j)
-                                bfr[ks][j] = BT ? read_frag<128, true>(lb + ((wn * WN) >> 7) * 16384, ((wn * WN) & 127) + 16 * j, ks, lane)
+                                bfr[ks][j] = BT ? tr_frag(lds_base + (uint32_t)(cur - smem) + b_region, tr_base, sw, b_chunk16 + 32u * j, ks)
                                                 : read_frag<BN, false>(lb, wn * WN + 16 * j, ks, lane);
                     }
                     bf16x8 af[2][2];
@@ -257,70 +305,96 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const GemmGroup g, const 
                     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
                         for (int ii = 0; ii < 2; ++ii) af[ks][ii] = read_frag<256, false>(la, wm * 128 + 16 * (2 * q + ii), ks, lane);
-                    if (q == 0) stage_group(I2{}, oth);
-                    else if (q == 1) stage_group(I3{}, oth);
-                    else if (q == 2) stage_group(I0{}, cur);
-                    else stage_group(I1{}, cur);
-                    if (q == 1) { if (!fresh) wait_vmcnt<W1>(); }
-                    if (q == 3) wait_vmcnt<W3>();
+                    if constexpr (!LATE) { stage_phase(q_, I0{}, cur, oth); stage_phase(q_, I1{}, cur, oth); }
+                    if constexpr (q == 1) {
+                        if (after_epi == 0) wait_vmcnt<W1>();
+                        else if (after_epi == NSIDE) wait_vmcnt<W1 + NSIDE>();
+                        else if (after_epi == 2 * NSIDE) wait_vmcnt<W1 + 2 * NSIDE>();
+                    }
+                    if constexpr (q == 3) wait_vmcnt<W3>();
                     asm volatile("s_barrier\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
                     __builtin_amdgcn_sched_barrier(0);
                     __builtin_amdgcn_s_setprio(1);
+                    constexpr int NM = 4 * TN;       // MFMAs of the phase: the two LDS-DMA loads go after the first and the second quarter
 #pragma unroll
-                    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                        for (int ii = 0; ii < 2; ++ii)
-#pragma unroll
-                            for (int j = 0; j < TN; ++j)
-                                acc[2 * q + ii][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ks][j], af[ks][ii], acc[2 * q + ii][j], 0, 0, 0);
+                    for (int t = 0; t < NM; ++t) {
+                        const int ks = t / (2 * TN), ii = (t / TN) & 1, j = t % TN;
+                        acc[2 * q + ii][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ks][j], af[ks][ii], acc[2 * q + ii][j], 0, 0, 0);
+                        if constexpr (LATE) {
+                            if (t == NM / 4 - 1) stage_phase(q_, I0{}, cur, oth);
+                            if (t == NM / 2 - 1) stage_phase(q_, I1{}, cur, oth);
+                        }
+                    }
                     __builtin_amdgcn_s_setprio(0);
                     __builtin_amdgcn_sched_barrier(0);
                     asm volatile("s_barrier" ::: "memory");
-                }
+                };
+                phase(I0{}); phase(I1{}); phase(I2{}); phase(I3{});
             } else {
                 bf16x8 bfr[TN];      // the B fragments of one k half: read in the half's first phase, kept for its second
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int ks = q >> 1, mh = q & 1;
+                auto phase = [&](auto q_) {
+                    constexpr int q = decltype(q_)::value;
+                    constexpr int ks = q >> 1, mh = q & 1;
                     __builtin_amdgcn_sched_barrier(0);
                     bf16x8 af[4];
-                    if (mh == 0) {
+                    uint32_t sw = tr_swz;
+                    asm volatile("" : "+v"(sw));
+                    const uint32_t slot = lds_base + (uint32_t)(cur - smem);
+                    if constexpr (mh == 0) {
 #pragma unroll
-                        for (int j = 0; j < TN; ++j)
-                            bfr[j] = read_frag<128, true>(lb + ((wn * WN) >> 7) * 16384, ((wn * WN) & 127) + 16 * j, ks, lane);
+                        for (int j = 0; j < TN; ++j) bfr[j] = tr_frag(slot + b_region, tr_base, sw, b_chunk16 + 32u * j, ks);
                     }
 #pragma unroll
-                    for (int ii = 0; ii < 4; ++ii) af[ii] = read_frag<128, true>(la + wm * 16384, 16 * (4 * mh + ii), ks, lane);
-                    if (q == 0) stage_group(I2{}, oth);
-                    else if (q == 1) stage_group(I3{}, oth);
-                    else if (q == 2) stage_group(I0{}, cur);
-                    else stage_group(I1{}, cur);
-                    if (q == 1) { if (!fresh) wait_vmcnt<W1>(); }
-                    if (q == 3) wait_vmcnt<W3>();
+                    for (int ii = 0; ii < 4; ++ii) af[ii] = tr_frag(slot + (uint32_t)wm * 16384u, tr_base, sw, 32u * (4 * mh + ii), ks);
+                    if constexpr (!LATE) { stage_phase(q_, I0{}, cur, oth); stage_phase(q_, I1{}, cur, oth); }
+                    if constexpr (q == 1) {
+                        if (after_epi == 0) wait_vmcnt<W1>();
+                        else if (after_epi == NSIDE) wait_vmcnt<W1 + NSIDE>();
+                        else if (after_epi == 2 * NSIDE) wait_vmcnt<W1 + 2 * NSIDE>();
+                    }
+                    if constexpr (q == 3) wait_vmcnt<W3>();
                     asm volatile("s_barrier\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
                     __builtin_amdgcn_sched_barrier(0);
                     __builtin_amdgcn_s_setprio(1);
+                    constexpr int NM = 4 * TN;
 #pragma unroll
-                    for (int ii = 0; ii < 4; ++ii)
-#pragma unroll
-                        for (int j = 0; j < TN; ++j)
-                            acc[4 * mh + ii][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[ii], acc[4 * mh + ii][j], 0, 0, 0);
-                    if (do_rowsum) {
-                        // af[wn] is row tile 4 mh + wn of this phase: one extra MFMA against an all-ones operand
-                        const bf16x8 a = wn == 0 ? af[0] : wn == 1 ? af[1] : wn == 2 ? af[2] : af[3];
-                        accb[mh] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, a, accb[mh], 0, 0, 0);
+                    for (int t = 0; t < NM; ++t) {
+                        const int ii = t / TN, j = t % TN;
+                        acc[4 * mh + ii][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[ii], acc[4 * mh + ii][j], 0, 0, 0);
+                        if constexpr (LATE) {
+                            if (t == NM / 4 - 1) stage_phase(q_, I0{}, cur, oth);
+                            if (t == NM / 2 - 1) stage_phase(q_, I1{}, cur, oth);
+                        }
+                    }
+                    if constexpr (RS) {
+                        // af[wn] is row tile 4 mh + wn of this phase: one extra MFMA against an all-ones operand (scalar branches
+                        // on the uniform wave column)
+                        switch (wn) {
+                            case 0: accb[mh] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[0], accb[mh], 0, 0, 0); break;
+                            case 1: accb[mh] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[1], accb[mh], 0, 0, 0); break;
+                            case 2: accb[mh] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[2], accb[mh], 0, 0, 0); break;
+                            default: accb[mh] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[3], accb[mh], 0, 0, 0); break;
+                        }
                     }
                     __builtin_amdgcn_s_setprio(0);
                     __builtin_amdgcn_sched_barrier(0);
                     asm volatile("s_barrier" ::: "memory");
-                }
+                };
+                phase(I0{}); phase(I1{}); phase(I2{}); phase(I3{});
             }
-            fresh = false;
+            after_epi = 0;
         };
 
-        for (int kt = 0; kt < cu.nkt; kt += 2) {
-            ktile(buf0, buf1);
-            ktile(buf1, buf0);
+        if (EC == 2 && do_rowsum) {
+            for (int kt = 0; kt < cu.nkt; kt += 2) {
+                ktile(std::bool_constant<EC == 2>{}, buf0, buf1);
+                ktile(std::bool_constant<EC == 2>{}, buf1, buf0);
+            }
+        } else {
+            for (int kt = 0; kt < cu.nkt; kt += 2) {
+                ktile(std::false_type{}, buf0, buf1);
+                ktile(std::false_type{}, buf1, buf0);
+            }
         }
 
         // ------------------------------------------------------------------ epilogue of this unit
@@ -332,10 +406,10 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const GemmGroup g, const 
         const int epi = p.epi, Mrows = p.M, Ncols = p.N, ldc = p.ldc;
         const float alpha = p.alpha_dev ? p.alpha * p.alpha_dev[0] : p.alpha;
         constexpr int UNITS = WN / 4;                 // 16-B units per parked row
-        constexpr int CPR = WN / 8;                   // 8-column chunks per row
         constexpr int RPU = 64 / CPR;                 // rows covered by the 64 lanes in one pass
         constexpr int U = 16 / RPU;                   // passes per 16-row round
-        constexpr int NSIDE = TM * U;
+        static_assert(NSIDE == TM * U, "epilogue geometry");
+        int nstores = 0;
         constexpr uint32_t kDrop = 0xFFFFFFF0u;       // >= every descriptor's extent: the access is dropped / reads 0
         auto park = [&](int i) {
             const int row = lane & 15;
@@ -346,7 +420,60 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const GemmGroup g, const 
             }
         };
         const bool atomic = p.split_k > 1;
-        if (EC == 2 && atomic) {
+        if constexpr (EC == 0) {
+            // bf16 outputs without side inputs, entirely in registers: v = alpha acc + bias in the MFMA layout (lane = row l & 15,
+            // 4 consecutive columns at 4 (l >> 4) of each 16 x 16 tile), bias out of the LDS copy made at kernel entry (no
+            // vector-memory load, so NOTHING has to be drained: the next unit's prefetch stays in flight and the stores queue
+            // behind it), packed to bf16, and v_permlane16_swap between the tiles of a column pair turns the 8-byte pieces of
+            // lanes l / l + 16 into 16 bytes per lane: every store instruction writes 16 rows x 64 contiguous bytes.
+            // (experiments build, BVC_GEMM_DEBUG bit 1: zero-record descriptors - every store is dropped by the range check while
+            //  the instruction stream, the counters and the waits stay: prices the stores)
+            const __amdgpu_buffer_rsrc_t rc = make_rsrc(p.C, BVC_DBG(g, 1) ? 0u : kDrop);
+            const __amdgpu_buffer_rsrc_t rc2 = make_rsrc(p.C2 ? p.C2 : p.C, BVC_DBG(g, 1) ? 0u : kDrop);
+            const AS3 float* lbias = (const AS3 float*)((AS3 char*)smem + 2 * TILE);
+            const int q4 = lane >> 4;
+            f32x4 bj[TN];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int nb = n0 + wn * WN + 16 * j + 4 * q4;            // < N rounded up to the tile: inside the LDS copy
+                bj[j] = *reinterpret_cast<const AS3 f32x4*>(lbias + nb);
+            }
+            const bool gelu2 = epi == EPI_GELU;
+            const bool relu = epi == EPI_RELU;
+            // this lane's 8 columns after the swap: tile 2 jp + (q4 & 1), columns 8 (q4 >> 1) .. + 7
+            const int ncol = n0 + wn * WN + 16 * (q4 & 1) + 8 * (q4 >> 1);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int m = m0 + wm * 128 + 16 * i + (lane & 15);
+#pragma unroll
+                for (int jp = 0; jp < TN / 2; ++jp) {
+                    float va[4], vb[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        va[e] = acc[i][2 * jp][e] * alpha + bj[2 * jp][e];
+                        vb[e] = acc[i][2 * jp + 1][e] * alpha + bj[2 * jp + 1][e];
+                        if (relu) { va[e] = fmaxf(va[e], 0.f); vb[e] = fmaxf(vb[e], 0.f); }
+                    }
+                    const int n = ncol + 32 * jp;
+                    const uint32_t o = (m < Mrows && n < Ncols) ? (uint32_t)(((size_t)m * ldc + n) * 2) : kDrop;
+                    auto emit = [&](__amdgpu_buffer_rsrc_t r) {
+                        uint32_t a0 = pack2bf(va[0], va[1]), a1 = pack2bf(va[2], va[3]);
+                        uint32_t b0 = pack2bf(vb[0], vb[1]), b1 = pack2bf(vb[2], vb[3]);
+                        const auto s0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
+                        const auto s1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
+                        // even lane rows: own tile-2jp columns, then lane + 16's; odd lane rows: lane - 16's tile-(2jp+1) columns, then own
+                        __builtin_amdgcn_raw_buffer_store_b128(u32x4{s0[0], s1[0], s0[1], s1[1]}, r, o, 0, 0);
+                    };
+                    emit(rc);
+                    if (gelu2) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { va[e] = gelu_f(va[e]); vb[e] = gelu_f(vb[e]); }
+                        emit(rc2);
+                    }
+                }
+            }
+            nstores = gelu2 ? 2 * NSIDE : NSIDE;
+        } else if (EC == 2 && atomic) {
             // split-K: f32 atomics, one dword per lane, whole contiguous rows per wave-instruction (256 B / two 128-B rows)
             float* cbase = reinterpret_cast<float*>(p.C);
 #pragma unroll
@@ -442,16 +569,7 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const GemmGroup g, const 
                             u32x4{pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])}, r, o, 0, 0);
                     };
                     if constexpr (EC == 0) {
-                        if (epi == EPI_RELU) {
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
-                        }
-                        store_bf16(rc, o2);
-                        if (epi == EPI_GELU) {
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
-                            store_bf16(rc2, o2);
-                        }
+                        // (handled above, in registers)
                     } else if constexpr (EC == 3) {
                         if (epi == EPI_DGELU) {
 #pragma unroll
@@ -524,7 +642,7 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const GemmGroup g, const 
         uid += nslots;
         if (uid >= x_hi) break;
         decode_unit<BN>(g, uid, cu);
-        fresh = !(EC == 2 && atomic);
+        after_epi = (EC == 2 && atomic) ? 0 : EC == 0 ? nstores : -1;
     }
     // drain the out-of-range tail of the stream, then pay back the stagger barrier
     wait_vmcnt<0>();
@@ -534,7 +652,8 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const GemmGroup g, const 
 // ------------------------------------------------------------------ host side
 template <int BN, bool AT, bool BT, int EC>
 static int launch_gemm8_one(const GemmGroup& g, int total, hipStream_t stream) {
-    constexpr size_t lds = 2 * (size_t)(256 + BN) * 64 * 2 + 8 * 16 * (BN / 4) * 4;    // 160 KiB (BN = 256) / 112 KiB (BN = 128)
+    // two K-tile slots + the epilogue region: 16 parked rows per wave (classes 1-3) or the bias copy of class 0 (32 KiB: N <= 8192)
+    constexpr size_t lds = 2 * (size_t)(256 + BN) * 64 * 2 + (EC == 0 ? (size_t)32768 : (size_t)8 * 16 * (BN / 4) * 4);
     static bool attr_set = false;
     if (!attr_set) {
         BVC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm8_kernel<BN, AT, BT, EC>),
@@ -581,6 +700,8 @@ int launch_gemm8(const GemmGroup& g, GemmLayout layout, int bn, hipStream_t stre
         if (p.rowsum && layout != GEMM_TN) return 1;
         // the f32-side epilogues keep 8 floats of side input per chunk in registers: 256 x 128 tiles only
         if (c == 1 && bn != 128) return 1;
+        // class 0 keeps the whole (tile-padded) bias vector in LDS (32 KiB): one problem, N up to 8192
+        if (c == 0 && (g.nprob != 1 || (size_t)((p.N + bn - 1) / bn) * bn * 4 > (size_t)32768)) return 1;
     }
     if (total <= 0) return 1;
 #define BVC_G8(BN_, AT_, BT_, EC_) return launch_gemm8_one<BN_, AT_, BT_, EC_>(g, total, stream)

@@ -26,6 +26,7 @@ for step in "$@"; do
     exp)   export BVC_EXTRA_HIPCC_FLAGS=-DBVC_EXPERIMENTS; run expbuild 400 python -c "import __graft_entry__ as g; g.build()" ;;
     noexp) unset BVC_EXTRA_HIPCC_FLAGS; run prodbuild 400 python -c "import __graft_entry__ as g; g.build()" ;;
     g8ab)  run g8ab 500 python tools/gemm8_ab.py ;;
+    g8store) run g8store 300 python tools/g8_store_cost.py ;;
     ops)   run ops 420 python -m pytest tests/test_gpu_ops.py -m gpu -q -p no:cacheprovider ;;
     model) run model 420 python -m pytest tests/test_gpu_videomae.py -m gpu -q -p no:cacheprovider ;;
     all)   run alltests 600 python -m pytest tests -m gpu -q -x -p no:cacheprovider ;;
@@ -85,6 +86,17 @@ for step in "$@"; do
            run pmc_gemm2 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_SALU SQ_INST_CYCLES_VMEM --output-format csv -d $OUT/pmcg/b -- python3 $R/tools/gemm_only.py
            cd $R
            run pmc_gemm_summary 60 python tools/pmc_summary.py $OUT/pmcg/a $OUT/pmcg/b $OUT/pmc_gemm_summary.txt ;;
+    pmc_g8) rm -rf $OUT/pmcg8; cd /tmp
+           for c in square8192 square8192_bn128 dec_qkv enc_fc1 square8192_128x128; do
+             export BVC_G8_CASE=$c
+             run pmc_g8_${c}_a 200 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA --output-format csv -d $OUT/pmcg8/$c/a -- python3 $R/tools/g8_only.py
+             run pmc_g8_${c}_b 200 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_SALU SQ_INST_CYCLES_VMEM --output-format csv -d $OUT/pmcg8/$c/b -- python3 $R/tools/g8_only.py
+             run pmc_g8_${c}_c 200 rocprofv3 --kernel-trace --pmc SQ_INSTS_VMEM SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_VMEM SQ_INSTS_SMEM SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_SCA GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmcg8/$c/c -- python3 $R/tools/g8_only.py
+             python3 $R/tools/pmc_summary.py $OUT/pmcg8/$c/a $OUT/pmcg8/$c/b $OUT/pmc_g8_$c.txt > /dev/null
+             python3 $R/tools/pmc_summary.py $OUT/pmcg8/$c/c $OUT/pmcg8/$c/c $OUT/pmc_g8_${c}_c.txt > /dev/null
+             find $OUT/pmcg8/$c -name "*.csv" -size +2M -delete
+           done
+           unset BVC_G8_CASE; cd $R; cat $OUT/pmc_g8_*.txt ;;
     *) echo "unknown step $step" ;;
   esac
 done

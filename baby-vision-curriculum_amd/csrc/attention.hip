@@ -62,7 +62,7 @@ __device__ __forceinline__ void stage64(__amdgpu_buffer_rsrc_t rs, int row0, int
         const int r = RPP * j + lane / CPR;
         const int c = (lane % CPR) ^ swz_dual<HD>(r);
         const uint32_t off = (uint32_t)(((size_t)(row0 + r) * ld + col0 + c * 8) * 2);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, LDS_PTR(lds + j * 1024), 16, off, 0, 0, 0);
+        glds16(rs, off, (uint32_t)(size_t)((AS3 char*)lds) + (uint32_t)j * 1024u);     // asm: see common.h (no compiler-made drain)
     }
 }
 
@@ -123,6 +123,12 @@ __device__ __forceinline__ int acc_row(int reg, int h) { return (reg & 3) + 8 * 
 
 // 8 consecutive bf16 of one row straight from HBM (row clamped by the caller)
 __device__ __forceinline__ bf16x8 load8(const bf16_t* p) { return *reinterpret_cast<const bf16x8*>(p); }
+
+// hipcc keeps its own count of the vector-memory loads it knows; the LDS-DMA of these kernels is inline asm it does not see.
+// Passing a plain load's result through an empty asm makes hipcc wait for that load HERE, before the first LDS-DMA is
+// issued - otherwise its wait lands at the first use inside the tile loop and (one in-order counter) drains the prefetch too.
+template <typename T>
+__device__ __forceinline__ void settle(T& v) { asm volatile("" : "+v"(v)); }
 
 __device__ __forceinline__ f32x16 zero16() {
     f32x16 z;
@@ -246,6 +252,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
         stage64<HD>(rs, krow0 + kt * 64, ld, D + head * HD, smem + stage * STG, wave, lane);
         stage64<HD>(rs, krow0 + kt * 64, ld, 2 * D + head * HD, smem + stage * STG + IMG, wave, lane);
     };
+#pragma unroll
+    for (int stq = 0; stq < HD / 16; ++stq) settle(qf[stq]);
     issue(0, 0);
     for (int kt = 0; kt < nkt; kt += 2) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -344,7 +352,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
     }
     del_q += __shfl_xor(del_q, 32, 64);
     if (h == 0 && qi < N) delta[(size_t)bh * N + qi] = del_q;      // the dK/dV kernel, launched after this one, reads it
-    const float nlse = -lse[(size_t)bh * N + qc];
+    float nlse = -lse[(size_t)bh * N + qc];
+#pragma unroll
+    for (int stq = 0; stq < HD / 16; ++stq) { settle(qf[stq]); settle(dof[stq]); }
+    settle(nlse); settle(del_q);
     f32x16 dq[HD / 32];
 #pragma unroll
     for (int t = 0; t < HD / 32; ++t) dq[t] = zero16();
@@ -462,6 +473,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const bf16_t* __r
 #pragma unroll
         for (int st = 0; st < HD / 16; ++st) { kf[st] = load8(krow + 16 * st); vf[st] = load8(krow + D + 16 * st); }
     }
+#pragma unroll
+    for (int stq = 0; stq < HD / 16; ++stq) { settle(kf[stq]); settle(vf[stq]); }
     f32x16 dk[HD / 32], dv[HD / 32];
 #pragma unroll
     for (int t = 0; t < HD / 32; ++t) { dk[t] = zero16(); dv[t] = zero16(); }
@@ -473,9 +486,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const bf16_t* __r
         stage64<HD>(rq, qrow0 + qt * 64, ld, head * HD, dst, wave, lane);
         stage64<HD>(rd, qrow0 + qt * 64, D, head * HD, dst + IMG, wave, lane);
         if (wave == 0)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rl, LDS_PTR(dst + 2 * IMG), 4, (uint32_t)(((size_t)bh * N + qt * 64 + lane) * 4), 0, 0, 0);
+            glds4(rl, (uint32_t)(((size_t)bh * N + qt * 64 + lane) * 4), (uint32_t)(size_t)((AS3 char*)dst) + 2 * IMG);
         if (wave == 1)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(re, LDS_PTR(dst + 2 * IMG + 256), 4, (uint32_t)(((size_t)bh * N + qt * 64 + lane) * 4), 0, 0, 0);
+            glds4(re, (uint32_t)(((size_t)bh * N + qt * 64 + lane) * 4), (uint32_t)(size_t)((AS3 char*)dst) + 2 * IMG + 256);
     };
     issue(0, 0);
     for (int qt = 0; qt < nqt; qt += 2) {

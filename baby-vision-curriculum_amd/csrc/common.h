@@ -66,6 +66,24 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, ui
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
 }
 
+// One LDS-DMA piece (64 lanes x 16 B -> 1 KiB of LDS at the wave-uniform byte address lds_addr) as INLINE ASM: hipcc must not
+// know that these loads write LDS.  With the builtin it orders every `ds_read_b64_tr_b16` behind an `s_waitcnt vmcnt(0)` (the
+// transposed-read intrinsic may alias anything), which drains the whole prefetch once per K step - measured 4x on the weight
+// gradient products of gemm8.hip, and present in every NN / TN instantiation of gemm_kernel / gemm_persist_kernel and in the three attention kernels (the next
+// tile's K/V prefetch was drained before the current tile's P V product) before round 2.  The data is ordered for the readers by the counted vmcnt + barrier protocol of the kernel alone.
+// M0 (the DMA's LDS base) is compiler-reserved: saved and restored inside the statement.
+__device__ __forceinline__ void glds16(__amdgpu_buffer_rsrc_t rs, uint32_t voff, uint32_t lds_addr) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(rs), "s"(lds_addr) : "memory");
+}
+// the 4-byte form (64 lanes x 4 B -> 256 B of LDS): per-row statistics next to an operand tile
+__device__ __forceinline__ void glds4(__amdgpu_buffer_rsrc_t rs, uint32_t voff, uint32_t lds_addr) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dword %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(rs), "s"(lds_addr) : "memory");
+}
+
 // ---------------------------------------------------------------- host side
 #include <string>
 namespace bvc {

@@ -40,17 +40,6 @@ __device__ __forceinline__ int swz_tr(int k) {
     else return (((k >> 1) & 1) | (((k >> 3) & 1) << 1)) << 1;                  // 128-B rows
 }
 
-// One LDS-DMA piece (64 lanes x 16 B -> 1 KiB of LDS at the wave-uniform byte address lds_addr) as INLINE ASM: hipcc must not
-// know that these loads write LDS.  With the builtin it orders every `ds_read_b64_tr_b16` behind an `s_waitcnt vmcnt(0)` (the
-// transposed-read intrinsic may alias anything), which drains the whole prefetch once per K step - measured 4x on the weight
-// gradient products of gemm8.hip, and present in every NN / TN instantiation of gemm_kernel / gemm_persist_kernel before round 2.  The data is ordered for the readers by the counted vmcnt + barrier protocol of the kernel alone.
-// M0 (the DMA's LDS base) is compiler-reserved: saved and restored inside the statement.
-__device__ __forceinline__ void glds16(__amdgpu_buffer_rsrc_t rs, uint32_t voff, uint32_t lds_addr) {
-    uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(voff), "s"(rs), "s"(lds_addr) : "memory");
-}
-
 // ------------------------------------------------------------------ HBM -> LDS staging of one operand tile
 // Non-transposed: rows r0..r0+BR-1 (output dim), k0..k0+63 of a [R][ld] array -> image [BR][64].
 // Transposed:     k rows k0..k0+63, columns r0..r0+BR-1 of a [Kc][ld] array    -> image [64][BR].

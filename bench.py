@@ -153,6 +153,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--torch-sgd", action="store_true", help="use torch.optim.SGD instead of the fused HIP update")
     ap.add_argument("--per-step", action="store_true", help="diagnostic: per-step HIP-event and host-enqueue times to stderr")
+    ap.add_argument("--bucket-mb", type=float, default=25.0, help="gradient all-reduce bucket size of the data-parallel wrapper")
     ap.add_argument("--stream-input", action="store_true",
                     help="feed every step a fresh uint8 batch from pinned host memory through the upload ring (copy stream + events) "
                          "instead of re-using clips resident in HBM; reported beside the resident-input number, never as `value`")
@@ -191,7 +192,8 @@ def main():
     torch.manual_seed(0)
     model = bvc.VideoMAEForPreTraining(bvc.VideoMAEConfig()).to(dev).train()
     model._ensure_flat(dev)
-    xmodel = bvc.DistributedDataParallel(model, device_ids=[local_rank], force_collectives=use_ddp) if use_ddp else model
+    xmodel = bvc.DistributedDataParallel(model, device_ids=[local_rank], force_collectives=use_ddp,
+                                         bucket_cap_mb=args.bucket_mb) if use_ddp else model
     # same constructor arguments as the reference's torch.optim.SGD (pretrain_videomae.py:187-189); the update is one
     # HIP launch over the flat parameter buffer (--torch-sgd switches back to torch.optim.SGD)
     SGD = torch.optim.SGD if args.torch_sgd else bvc.optim.SGD
@@ -280,7 +282,7 @@ def main():
             step()
         torch.cuda.synchronize()
         rep = xmodel.bucket_report()
-        comm = {"backend": "rccl (torch.distributed nccl)", "ranks": dist.get_world_size(), "bucket_cap_mb": 25.0,
+        comm = {"backend": "rccl (torch.distributed nccl)", "ranks": dist.get_world_size(), "bucket_cap_mb": args.bucket_mb,
                 "buckets_last_step": rep[-1] if rep else []}
         xmodel.profile_buckets = False
     stream_info = None

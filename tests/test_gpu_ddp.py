@@ -73,3 +73,109 @@ def test_ddp_wrapper_rccl_single_rank():
         assert stats.dec_last_layer > 0
     finally:
         dist.destroy_process_group()
+
+
+def _rccl_group(port):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+
+
+def test_ddp_jepa_three_wraps_rccl_single_rank():
+    """pretrain_jepa.py:302-304 with bvc's class: encoder, predictor and target encoder wrapped separately.  With one rank the
+    collectives are identities, so gradients must equal the unwrapped modules'; the predictor reports its gradient ranges
+    per block (bvc_predictor_backward_cb), the encoder per layer, and every byte of both buffers is reduced exactly once."""
+    import copy
+    from oracle import jepa_oracle as jo
+    _rccl_group(29534)
+    try:
+        cfg = jo.TINY
+        B, n_ctx, n_pred = 3, 6, 4
+        enc_p = jo.make_params(jo.encoder_shapes(cfg), cfg, 0)
+        pred_p = jo.make_params(jo.predictor_shapes(cfg), cfg, 50)
+        imgs, m_enc, m_pred = jo.synthetic_inputs(cfg, B, 0, n_ctx, n_pred)
+        x = imgs.to(dev)
+        me, mp = [m.to(dev) for m in m_enc], [m.to(dev) for m in m_pred]
+        kw = dict(img_size=[cfg.image_size], patch_size=cfg.patch_size, num_frames=cfg.num_frames, tubelet_size=cfg.tubelet_size,
+                  embed_dim=cfg.embed_dim, depth=cfg.depth, num_heads=cfg.num_heads, mlp_ratio=cfg.mlp_ratio)
+
+        def build():
+            enc = bvc.jepa.VisionTransformer(**kw)
+            enc.load_state_dict(enc_p)
+            tgt = copy.deepcopy(enc)
+            pred = bvc.jepa.vit_predictor(sequence_shape=enc.sequence_shape, embed_dim=cfg.embed_dim, predictor_embed_dim=cfg.pred_dim,
+                                          depth=cfg.pred_depth, num_heads=enc.num_heads)
+            pred.load_state_dict(pred_p)
+            for p in tgt.parameters():
+                p.requires_grad = False
+            return enc.to(dev), pred.to(dev), tgt.to(dev)
+
+        def step(enc, pred, tgt):
+            with torch.no_grad():
+                h = bvc.jepa.select_targets(tgt(x), mp)
+            loss = bvc.jepa.smooth_l1_loss(pred(enc(x, me), me, mp), h)
+            loss.backward()
+            torch.cuda.synchronize()
+            return float(loss)
+
+        enc0, pred0, tgt0 = build()
+        ref_loss = step(enc0, pred0, tgt0)
+        enc, pred, tgt = build()
+        DDP = bvc.DistributedDataParallel
+        wenc = DDP(enc, device_ids=[0], static_graph=True, bucket_cap_mb=0.05, force_collectives=True)
+        wpred = DDP(pred, device_ids=[0], static_graph=True, bucket_cap_mb=0.05, force_collectives=True)
+        wtgt = DDP(tgt, device_ids=[0], force_collectives=True)
+        loss = step(wenc, wpred, wtgt)
+        assert abs(loss - ref_loss) / ref_loss < 1e-6
+        assert G.rel_err(enc.flat_grads(), enc0.flat_grads()) < 1e-6 and G.rel_err(pred.flat_grads(), pred0.flat_grads()) < 1e-6
+        for w, n in ((wenc, enc.flat_grads().numel()), (wpred, pred.flat_grads().numel())):
+            cov = sorted(w.reduced_ranges)
+            assert len(cov) >= 2, cov                         # more than one bucket: ranges arrived per block, not once at the end
+            assert cov[0][0] == 0 and cov[-1][1] == n and all(a[1] == b[0] for a, b in zip(cov, cov[1:]))
+        bvc.jepa.ema_update(enc, tgt, 0.99)
+        torch.cuda.synchronize()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_ddp_composite_simclr_vit_rccl_single_rank():
+    """pretrain_simclr.py:227-228 for the config-5 model: SimCLRViT = flat ViT trunk + ordinary-parameter head under ONE wrapper
+    (trunk gradients through the bucket hooks, head gradients through the coalesced all-reduce), global InfoNCE behind
+    AllGather.  One rank: must reproduce the unwrapped model bit for bit in the loss and to round-off in the gradients."""
+    _rccl_group(29535)
+    try:
+        torch.manual_seed(0)
+        B = 8
+
+        def build():
+            m = bvc.simclr.SimCLRViT.__new__(bvc.simclr.SimCLRViT)
+            torch.nn.Module.__init__(m)
+            m.trunk = bvc.jepa.VisionTransformer(img_size=[64], patch_size=16, num_frames=1, tubelet_size=1, embed_dim=128, depth=2, num_heads=2)
+            m.fc = bvc.simclr.ProjectionHead(128, 128)
+            return m
+
+        ref = build()
+        state = {k: v.clone() for k, v in ref.state_dict().items()}
+        ref.to(dev).train()
+        imgs = torch.randn(2 * B, 3, 64, 64, device=dev)
+        masks = bvc.simclr.make_masks(B, dev)
+        l0 = bvc.simclr.global_info_nce_loss(0.1, masks, ref(imgs))
+        l0.backward()
+        torch.cuda.synchronize()
+        model = build()
+        model.load_state_dict(state)
+        model.to(dev).train()
+        ddp = bvc.DistributedDataParallel(model, device_ids=[0], output_device=0, find_unused_parameters=False, bucket_cap_mb=0.05,
+                                          force_collectives=True)
+        assert len(ddp._flats) == 1 and len(ddp._loose_grad) == 4          # trunk + fc.0.weight / bias, fc.2.weight / bias
+        l1 = bvc.simclr.global_info_nce_loss(0.1, masks, ddp(imgs))
+        l1.backward()
+        torch.cuda.synchronize()
+        assert float(l1) == float(l0)
+        assert G.rel_err(model.trunk.flat_grads(), ref.trunk.flat_grads()) < 1e-6
+        for (k, p), (_k, q) in zip(model.fc.named_parameters(), ref.fc.named_parameters()):
+            assert G.rel_err(p.grad, q.grad) < 1e-6, k
+        cov = sorted(ddp.reduced_ranges)
+        assert cov[0][0] == 0 and cov[-1][1] == model.trunk.flat_grads().numel()
+    finally:
+        dist.destroy_process_group()

@@ -158,6 +158,56 @@ def test_simclr_vit_composition_matches_oracle():
         assert G.rel_err(hn[k].grad.cpu(), hp[k].grad) < 8e-2, k
 
 
+def test_simclr_vit_b_composition_matches_oracle():
+    """The same composition at BASELINE config 5's model size: ViT-B/16 (768 wide, 12 layers, 12 heads, 196 tokens of one 224^2
+    frame) + token mean + the 768-wide head + info_nce_loss, 4 pairs.  Loss 1e-3; features 2e-2; gradient norms of the trunk's
+    first / last qkv weights (the predictive grad_logger probes) and of the patch embedding 3e-2 (bf16 operands through 12 layers
+    and a ReLU head; the per-tensor comparison against a bf16-operand oracle is made at head level in
+    test_projection_head_forward_backward)."""
+    from oracle import jepa_oracle as jo
+    cfg = jo.JepaConfig(num_frames=1)          # ViT-B defaults: 224, patch 16, 768 / 12 / 12
+    B, D = 4, cfg.embed_dim
+    enc_p = jo.make_params(jo.encoder_shapes(cfg), cfg, seed=4)
+    head_p = so.head_params(D, D, seed=9)
+    g = torch.Generator().manual_seed(22)
+    imgs = torch.randn(2 * B, cfg.in_chans, cfg.image_size, cfg.image_size, generator=g)
+    ep = {k: v.clone().requires_grad_(k != "pos_embed") for k, v in enc_p.items()}
+    hp = {k: v.clone().requires_grad_(True) for k, v in head_p.items()}
+    tok = jo.encoder_forward(cfg, ep, imgs.unsqueeze(1))
+    feats = so.head_forward(tok.mean(1), hp["0.weight"], hp["0.bias"], hp["2.weight"], hp["2.bias"])
+    ref = so.info_nce_loss(0.1, so.make_masks(B), feats)
+    # Gradients are compared against the SAME f32 trunk under a head whose GEMM operands are rounded to bf16
+    # (so.head_forward_bf16_operands): the head's ReLU gates are then decided on the numbers the device sees.  Against the pure
+    # f32 head ~0.1 % of the gates differ, the head's dX is off by 4-6 % (measured in test_projection_head_forward_backward) and
+    # every trunk gradient inherits that through 1/T = 10: 0.14 relative L2 in total here - a property of bf16 operands at a
+    # ReLU, not of the kernels.  The f32 oracle still pins the loss and the features.
+    feats16 = so.head_forward_bf16_operands(tok.mean(1), hp["0.weight"], hp["0.bias"], hp["2.weight"], hp["2.bias"])
+    so.info_nce_loss(0.1, so.make_masks(B), feats16).backward()
+
+    model = bvc.simclr.SimCLRViT("vit_base", image_size=224)
+    model.trunk.load_state_dict(enc_p)
+    model.fc.load_state_dict(head_p)
+    model.to(dev).train()
+    out = model(imgs.to(dev))
+    assert tuple(out.shape) == (2 * B, D)
+    loss = bvc.simclr.global_info_nce_loss(0.1, bvc.simclr.make_masks(B, dev), out)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert abs(float(loss) - float(ref)) / abs(float(ref)) < 1e-3, (float(loss), float(ref))
+    assert G.rel_err(out.detach().cpu(), feats.detach()) < 2e-2
+    named = dict(model.trunk.named_parameters())
+    for k in ("blocks.0.attn.qkv.weight", "blocks.11.attn.qkv.weight", "patch_embed.proj.weight"):
+        gn, rn = float(named[k].grad.norm()), float(ep[k].grad.norm())
+        assert abs(gn - rn) / rn < 3e-2, (k, gn, rn)
+    num = sum(float((named[k].grad.cpu() - ep[k].grad).double().pow(2).sum()) for k in ep if ep[k].grad is not None)
+    den = sum(float(ep[k].grad.double().pow(2).sum()) for k in ep if ep[k].grad is not None)
+    print(f"SimCLR ViT-B composition: trunk gradient rel L2 vs bf16-operand-head oracle {(num / den) ** 0.5:.3e}")
+    # measured 7.7e-2 (0.138 against the pure-f32 head): the device's trunk output itself carries bf16 noise of ~1e-2 through 12
+    # layers, so a share of the head's gates still differs from any CPU oracle's; the probes above (3e-2) and the loss (1e-3) are
+    # the pinned quantities, this aggregate is a regression guard
+    assert (num / den) ** 0.5 < 1.2e-1, (num / den) ** 0.5
+
+
 def test_token_mean_forward_backward():
     x = torch.randn(5, 37, 192, device=dev, requires_grad=True)
     y = bvc.jepa.token_mean(x)

@@ -27,6 +27,26 @@ for step in "$@"; do
     noexp) unset BVC_EXTRA_HIPCC_FLAGS; run prodbuild 400 python -c "import __graft_entry__ as g; g.build()" ;;
     g8ab)  run g8ab 500 python tools/gemm8_ab.py ;;
     g8store) run g8store 300 python tools/g8_store_cost.py ;;
+    # forced data-parallel path on ONE GPU (world size 1 over RCCL: every fence, stream hop and collective launch of the N-GPU job,
+    # no bytes on xGMI): overhead of the wrapper per bucket size, next to the plain run
+    ddpsweep) run ddp_plain 200 python bench.py --no-cpu-baseline --steps 20
+              for mb in 5 25 50 100 400; do BVC_FORCE_DDP=1 run ddp_mb$mb 200 python bench.py --no-cpu-baseline --steps 20 --bucket-mb $mb; done
+              python3 - <<'PY'
+import json, glob, re
+rows = []
+for f in ["gpurun_out/ddp_plain.log"] + sorted(glob.glob("gpurun_out/ddp_mb*.log"), key=lambda x: int(re.findall(r"mb(\d+)", x)[0])):
+    try:
+        d = json.loads(open(f).read().strip().splitlines()[-1])
+    except Exception as e:
+        rows.append(f"{f}: unreadable ({e})"); continue
+    c = d.get("comm")
+    nb = len(c["buckets_last_step"]) if c else 0
+    rows.append(f"{f.split('/')[-1]:16s} {d['value']:8.1f} clips/s {d['ms_per_step']:7.3f} ms/step  buckets {nb}" +
+                (f"  cap {c['bucket_cap_mb']} MB, per-bucket ms {[b['ms'] for b in c['buckets_last_step']][:4]}..." if c else ""))
+open("gpurun_out/ddp_bucket_sweep.txt", "w").write("\n".join(rows) + "\n")
+print("\n".join(rows))
+PY
+              ;;
     ops)   run ops 420 python -m pytest tests/test_gpu_ops.py -m gpu -q -p no:cacheprovider ;;
     model) run model 420 python -m pytest tests/test_gpu_videomae.py -m gpu -q -p no:cacheprovider ;;
     all)   run alltests 600 python -m pytest tests -m gpu -q -x -p no:cacheprovider ;;

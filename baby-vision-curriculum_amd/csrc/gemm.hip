@@ -561,6 +561,9 @@ static int pick_gemm8(const GemmProblem* probs, int nprob, GemmLayout layout) {
     const bool bf = p.epi == EPI_BF16 || p.epi == EPI_GELU || p.epi == EPI_RELU;
     const bool gated = p.epi == EPI_DGELU || p.epi == EPI_DRELU;
     if (!bf && !gated) return -1;
+    // one workgroup per CU pays its launch, prologue and tail once per launch: below ~45 GFLOP (~60 us) the 128 x 128 kernels with
+    // two workgroups per CU win on every product (profiles/r02_e_gemm8_ab_b16.txt: at 16 clips gemm8 loses 5-50 % everywhere)
+    if (2.0 * p.M * p.N * p.K < 45e9) return -1;
     const int t256 = ((p.M + 255) / 256) * ((p.N + 255) / 256), t128 = ((p.M + 255) / 256) * ((p.N + 127) / 128);
     if (t256 >= 448 && !(gated && p.K <= 512) && !(layout == GEMM_NN && bf)) return 10;
     if (layout == GEMM_NN && bf && p.K >= 1024 && t128 >= 224) return 11;

@@ -265,9 +265,6 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const GemmGroup g, const 
     // prefetched loads without draining them (vmcnt is one in-order counter), so the wait counts them as younger operations.
     int after_epi = 0;
 
-    bf16x8 ones;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) ones[e] = (short)0x3F80;
 
     while (true) {
         const GemmProblem& p = g.prob[cu.pi];
@@ -276,13 +273,12 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const GemmGroup g, const 
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        f32x4 accb[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+        float rsum[2] = {0.f, 0.f};
         const bool do_rowsum = EC == 2 && p.rowsum != nullptr && cu.n0 == 0;   // bias gradient: wave wn takes row tiles wn and 4 + wn
 
         // one K tile out of LDS slot `cur`; `oth` is the other slot
         auto ktile = [&](auto rs_, char* cur, char* oth) {
-            constexpr bool RS = decltype(rs_)::value;       // with the fused bias-gradient MFMA (its own copy of the K loop: a
-                                                            // branch inside the MFMA cluster cost ~48 live registers)
+            constexpr bool RS = decltype(rs_)::value;       // weight-gradient instantiation: may fuse the bias gradient
             const char* la = cur;
             const char* lb = cur + A_BYTES;
             if constexpr (!AT) {
@@ -366,15 +362,27 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const GemmGroup g, const 
                             if (t == NM / 2 - 1) stage_phase(q_, I1{}, cur, oth);
                         }
                     }
-                    if constexpr (RS) {
-                        // af[wn] is row tile 4 mh + wn of this phase: one extra MFMA against an all-ones operand (scalar branches
-                        // on the uniform wave column)
+                    if (RS && do_rowsum) {
+                        // bias gradient db[m] = sum_k A(m, k): wave column wn sums the fragment of row tile 4 mh + wn it has in
+                        // registers anyway (16 vector instructions per phase, no extra MFMA, no extra accumulator tile: the
+                        // all-ones-operand MFMA this replaces cost ~45 live registers and made the 256 x 256 instantiation
+                        // spill).  Lane l holds 8 k values of row l & 15; the k groups are folded by two shuffles at the end.
+                        bf16x8 a;
                         switch (wn) {
-                            case 0: accb[mh] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[0], accb[mh], 0, 0, 0); break;
-                            case 1: accb[mh] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[1], accb[mh], 0, 0, 0); break;
-                            case 2: accb[mh] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[2], accb[mh], 0, 0, 0); break;
-                            default: accb[mh] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[3], accb[mh], 0, 0, 0); break;
+                            case 0: a = af[0]; break;
+                            case 1: a = af[1]; break;
+                            case 2: a = af[2]; break;
+                            default: a = af[3]; break;
                         }
+                        union { bf16x8 v; uint32_t u[4]; } w;
+                        w.v = a;
+                        float t0 = 0.f, t1 = 0.f;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            t0 += __uint_as_float(w.u[e] << 16);
+                            t1 += __uint_as_float(w.u[e] & 0xffff0000u);
+                        }
+                        rsum[mh] += t0 + t1;
                     }
                     __builtin_amdgcn_s_setprio(0);
                     __builtin_amdgcn_sched_barrier(0);
@@ -385,16 +393,9 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const GemmGroup g, const 
             after_epi = 0;
         };
 
-        if (EC == 2 && do_rowsum) {
-            for (int kt = 0; kt < cu.nkt; kt += 2) {
-                ktile(std::bool_constant<EC == 2>{}, buf0, buf1);
-                ktile(std::bool_constant<EC == 2>{}, buf1, buf0);
-            }
-        } else {
-            for (int kt = 0; kt < cu.nkt; kt += 2) {
-                ktile(std::false_type{}, buf0, buf1);
-                ktile(std::false_type{}, buf1, buf0);
-            }
+        for (int kt = 0; kt < cu.nkt; kt += 2) {
+            ktile(std::bool_constant<EC == 2>{}, buf0, buf1);
+            ktile(std::bool_constant<EC == 2>{}, buf1, buf0);
         }
 
         // ------------------------------------------------------------------ epilogue of this unit
@@ -474,18 +475,21 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const GemmGroup g, const 
             }
             nstores = gelu2 ? 2 * NSIDE : NSIDE;
         } else if (EC == 2 && atomic) {
-            // split-K: f32 atomics, one dword per lane, whole contiguous rows per wave-instruction (256 B / two 128-B rows)
-            float* cbase = reinterpret_cast<float*>(p.C);
+            // split-K: f32 atomics, one dword per lane, whole contiguous rows per wave-instruction (256 B / two 128-B rows: the shape
+            // the memory-side atomic units take at full rate), through a buffer descriptor (32-bit offsets, dropped when out of range)
+            const __amdgpu_buffer_rsrc_t rca = make_rsrc(p.C, kDrop);
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 park(i);
-#pragma unroll 4
-                for (int idx = lane; idx < 16 * WN; idx += 64) {
+#pragma unroll
+                for (int t = 0; t < 16 * WN / 64; ++t) {
+                    const int idx = t * 64 + lane;
                     const int row = idx / WN, col = idx % WN;
                     const int m = m0 + wm * 128 + 16 * i + row, n = n0 + wn * WN + col;
                     const int unit = (col >> 2) ^ (row & (UNITS - 1));
                     const float v = *reinterpret_cast<const AS3 float*>(wl + row * (WN * 4) + unit * 16 + (col & 3) * 4) * alpha;
-                    if (m < Mrows && n < Ncols) atomicAdd(cbase + (size_t)m * ldc + n, v);
+                    const uint32_t o = (m < Mrows && n < Ncols) ? (uint32_t)(((size_t)m * ldc + n) * 4) : kDrop;
+                    __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(v, rca, o, 0, 0);
                 }
             }
         } else {
@@ -632,11 +636,14 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const GemmGroup g, const 
                 }
             }
         }
-        if (do_rowsum && (lane >> 4) == 0) {
+        if (do_rowsum) {
 #pragma unroll
             for (int mh = 0; mh < 2; ++mh) {
+                float v = rsum[mh];
+                v += __shfl_xor(v, 16, 64);
+                v += __shfl_xor(v, 32, 64);
                 const int m = m0 + wm * 128 + 16 * (4 * mh + wn) + lane;
-                if (m < p.M) atomicAdd(p.rowsum + m, accb[mh][0] * alpha);
+                if ((lane >> 4) == 0 && m < p.M) atomicAdd(p.rowsum + m, v * alpha);
             }
         }
         uid += nslots;

@@ -149,23 +149,31 @@ int plan_dw(GemmProblem* g, int n) {
     static const int bm[3] = {128, 128, 64}, bn[3] = {128, 64, 64};
     int ksteps = 1 << 30;
     for (int i = 0; i < n; ++i) ksteps = std::min(ksteps, (g[i].K + 63) / 64);
-    // 256 x 128 tiles of the 256-row persistent kernel (gemm8.hip, tile config 11): one workgroup per CU walks its units as one
-    // stream of K tiles, so the split is chosen for ~230 units on the 256 CUs (encoder layer: 216 units unsplit, decoder layer:
-    // 57 x 4).  Same-process A/B at 64 clips (profiles/r02_a_gemm8_ab_b64.txt): encoder group 187 vs 241 us, decoder 469 vs 553.
+    // The 256-row persistent kernel (gemm8.hip; tile config 10 = 256 x 256, 11 = 256 x 128): one workgroup per CU walks its units
+    // (tile x K split) as one stream of K tiles, so the split is chosen for ~230 units on the 256 CUs, at least 16 K tiles each.
+    // Same-process A/B at 64 clips (profiles/r02_e_gemm8_ab_b64.txt): encoder layer 256 x 256 split 2 (216 units) 181 us vs
+    // 256 x 128 unsplit 218 us vs the 128 x 128 kernel 220 us; decoder layer 256 x 256 split 6 (228 units) 549 us vs 626 us.
     static const bool no_g8 = getenv("BVC_GEMM_NO_G8") != nullptr;
     if (!no_g8) {
-        int units = 0;
         bool ok = true;
+        double flops = 0.0;
         for (int i = 0; i < n; ++i) {
-            units += ((g[i].M + 255) / 256) * ((g[i].N + 127) / 128);
             ok = ok && g[i].epi == EPI_F32 && g[i].a_bytes < 0x80000000u && g[i].b_bytes < 0x80000000u;
+            flops += 2.0 * g[i].M * g[i].N * g[i].K;
         }
-        if (ok && units >= 40 && ksteps >= 16) {
-            int split = std::max(1, (232 + units / 2) / units);
-            split = std::min(split, std::max(1, ksteps / 16));
-            if (units * split >= 160) {
-                for (int i = 0; i < n; ++i) g[i].split_k = split;
-                return 11;
+        // short launches stay on the 128 x 128 kernel (at 16 clips: encoder layer 53 vs 85 us, decoder layer 139 vs 151 us,
+        // profiles/r02_e_gemm8_ab_b16.txt): one workgroup per CU needs a long stream to amortise its prologue and tail
+        if (ok && ksteps >= 16 && flops >= 140e9) {
+            for (int t = 0; t < 2; ++t) {            // prefer the bigger tile when it still fills the chip
+                const int bnw = t == 0 ? 256 : 128;
+                int units = 0;
+                for (int i = 0; i < n; ++i) units += ((g[i].M + 255) / 256) * ((g[i].N + bnw - 1) / bnw);
+                int split = std::max(1, (232 + units / 2) / units);
+                split = std::min(split, std::max(1, ksteps / 16));
+                if (units >= 16 && units * split >= (t == 0 ? 200 : 160) && units * split <= 272) {
+                    for (int i = 0; i < n; ++i) g[i].split_k = split;
+                    return t == 0 ? 10 : 11;
+                }
             }
         }
     }

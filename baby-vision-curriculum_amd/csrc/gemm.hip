@@ -546,12 +546,15 @@ int launch_gemm_persist(const GemmGroup& g, GemmLayout layout, int cfg, hipStrea
 int launch_gemm8(const GemmGroup& g, GemmLayout layout, int bn, hipStream_t stream);
 
 // Which products go to the 256-row persistent kernel (gemm8.hip) when the caller leaves the tile choice open.  Fitted to the
-// same-process A/B of every product of the step (profiles/r02_a_gemm8_ab_b64.txt, tools/gemm8_ab.py): its K loop runs ~1.2 PFLOP/s
-// against ~0.8 for the 128 x 128 kernels, but it is ONE workgroup per CU - a launch needs about two full rounds of tiles, and
-// a heavy epilogue is not hidden by a second resident workgroup:
-//   * 256 x 256: bf16-output epilogues with >= 448 tiles (encoder fc1 / dX-fc2 at 64 clips, every wide decoder product),
-//     except GELU' at short K (the epilogue then outweighs the K loop);
-//   * 256 x 128: input-gradient products (NN, plain bf16 output) with K >= 1024 and >= 224 tiles.
+// same-process A/Bs of every product of the step at 16, 64 and 256 clips (profiles/r02_e_gemm8_ab_b{16,64,256}.txt, tools/gemm8_ab.py):
+// its K loop runs ~1.2 PFLOP/s against ~0.8 for the 128 x 128 kernels, but it is ONE workgroup per CU - a launch needs about two
+// full rounds of tiles and ~45 GFLOP to amortise prologue and tail, and an epilogue is not hidden by a second resident workgroup:
+//   * 256 x 256: plain bf16-output epilogues (BF16 / GELU / RELU) with >= 448 tiles whose last column tile is at least 85 % full
+//     (encoder qkv / fc1 / dX at >= 64 clips, decoder qkv / fc1: -20 ... -27 % at 256 clips, -5 ... -10 % at 64);
+//   * 256 x 128: input-gradient products (NN, bf16 out) and residual products (f32 + residual) with K >= 1024 and >= 224 tiles
+//     when the 256-wide tile would be half empty (decoder N = 384: dX-fc1, dX-qkv, fc2);
+//   * never: GELU' / ReLU' (their side-input epilogue still parks through LDS and drains the prefetch: no gain measured),
+//     launches below 45 GFLOP (at 16 clips gemm8 loses 5-50 % on every product).
 // Returns 10 / 11 (tile configs) or -1.
 static int pick_gemm8(const GemmProblem* probs, int nprob, GemmLayout layout) {
     static const bool off = getenv("BVC_GEMM_NO_G8") != nullptr;
@@ -559,14 +562,13 @@ static int pick_gemm8(const GemmProblem* probs, int nprob, GemmLayout layout) {
     const GemmProblem& p = probs[0];
     if (p.split_k != 1 || p.K % 64 != 0) return -1;
     const bool bf = p.epi == EPI_BF16 || p.epi == EPI_GELU || p.epi == EPI_RELU;
-    const bool gated = p.epi == EPI_DGELU || p.epi == EPI_DRELU;
-    if (!bf && !gated) return -1;
-    // one workgroup per CU pays its launch, prologue and tail once per launch: below ~45 GFLOP (~60 us) the 128 x 128 kernels with
-    // two workgroups per CU win on every product (profiles/r02_e_gemm8_ab_b16.txt: at 16 clips gemm8 loses 5-50 % everywhere)
+    const bool resid = p.epi == EPI_RESID && layout == GEMM_NT;
+    if (!bf && !resid) return -1;
     if (2.0 * p.M * p.N * p.K < 45e9) return -1;
-    const int t256 = ((p.M + 255) / 256) * ((p.N + 255) / 256), t128 = ((p.M + 255) / 256) * ((p.N + 127) / 128);
-    if (t256 >= 448 && !(gated && p.K <= 512) && !(layout == GEMM_NN && bf)) return 10;
-    if (layout == GEMM_NN && bf && p.K >= 1024 && t128 >= 224) return 11;
+    const int tm = (p.M + 255) / 256, tn256 = (p.N + 255) / 256, tn128 = (p.N + 127) / 128;
+    const bool full256 = (double)p.N >= 0.85 * 256.0 * tn256;
+    if (bf && full256 && tm * tn256 >= 448) return 10;
+    if ((bf ? layout == GEMM_NN : p.N <= 384) && p.K >= 1024 && tm * tn128 >= (resid ? 1024 : 224)) return 11;
     return -1;
 }
 

@@ -147,9 +147,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=64,
-                    help="clips per GPU.  SURVEY 8(d) names 16 (the reference's slurm default), 32 and 64; 64 is the default here "
-                         "because it is the fastest of the three on MI355X (profiles/r01_d_batch_sweep.txt)")
+    ap.add_argument("--batch", type=int, default=256,
+                    help="clips per GPU.  Throughput grows with the per-GPU batch (profiles/r02_f_batch_sweep.txt: 16 / 64 / 128 / 256 "
+                         "clips -> 0.15 / 0.20 / 0.21 / 0.22 of the MFMA roof) and 288 GB of HBM holds far more than the reference's "
+                         "16 clips (slurm_dev_def.bash:52), so the default is 256 (~40 GB); BASELINE.md lists 16 and 64 as well")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--torch-sgd", action="store_true", help="use torch.optim.SGD instead of the fused HIP update")
     ap.add_argument("--per-step", action="store_true", help="diagnostic: per-step HIP-event and host-enqueue times to stderr")

@@ -608,6 +608,15 @@ int launch_gemm(const GemmProblem* probs, int nprob, GemmLayout layout, int tile
                         "launch_gemm: split_k needs an accumulating f32 epilogue");
         g.prob[i] = p;
         g.panel[i] = pick_panel(p, cfg, layout);
+        if ((cfg == 10 || cfg == 11) && layout == GEMM_TN && BVC_EXP_ENV("BVC_G8_TN_LEGACY_WALK") == nullptr) {
+            // weight gradients on the persistent kernel: K splits SLOWEST, tiles row-major inside a split.  An XCD's ~32 resident
+            // units are then the tiles of one or two K ranges of one problem, which share their dY / X slices through its L2; with
+            // the splits fastest (the 128 x 128 kernel's walk) neighbours share nothing and every unit streams its own slices
+            // from HBM: 15.6 GB per decoder layer at 256 clips for 4.5 GB of operands (profiles/r02_f_dw_walk_ab.txt).
+            int bm, bn;
+            tile_dims(cfg, bm, bn);
+            g.panel[i] = (p.N + bn - 1) / bn;
+        }
         g.tile_start[i] = total;
         total += tiles_for(p, cfg) * p.split_k;
     }

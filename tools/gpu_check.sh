@@ -27,6 +27,7 @@ for step in "$@"; do
     noexp) unset BVC_EXTRA_HIPCC_FLAGS; run prodbuild 400 python -c "import __graft_entry__ as g; g.build()" ;;
     g8ab)  run g8ab 500 python tools/gemm8_ab.py ;;
     g8store) run g8store 300 python tools/g8_store_cost.py ;;
+    dwwalk) run dwwalk 300 python tools/dw_walk_ab.py ;;
     # forced data-parallel path on ONE GPU (world size 1 over RCCL: every fence, stream hop and collective launch of the N-GPU job,
     # no bytes on xGMI): overhead of the wrapper per bucket size, next to the plain run
     ddpsweep) run ddp_plain 200 python bench.py --no-cpu-baseline --steps 20

@@ -75,15 +75,15 @@ PY
     encode) run encode 300 python tools/bench_encode.py ;;
     simclr) run simclr 400 python tools/bench_simclr.py ;;
     prof)  rm -rf $OUT/prof; cd /tmp
-           run prof 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --batch ${BVC_BATCH:-16}
+           run prof 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --batch ${BVC_BATCH:-256}
            cd $R
            find $OUT/prof -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/kernel_stats.csv
            find $OUT/prof -name "*kernel_trace.csv" -size +20M -delete ;;
     traffic) rm -rf $OUT/pmct; cd /tmp
-           run traffic_rd 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmct/rd -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --batch ${BVC_BATCH:-16}
-           run traffic_wr 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmct/wr -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --batch ${BVC_BATCH:-16}
+           run traffic_rd 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmct/rd -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --batch ${BVC_BATCH:-256}
+           run traffic_wr 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmct/wr -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --batch ${BVC_BATCH:-256}
            cd $R
-           run traffic 60 python tools/pmc_traffic.py $OUT/pmct/rd $OUT/pmct/wr 3 ${BVC_BATCH:-16} $OUT/traffic_b${BVC_BATCH:-16}.json
+           run traffic 60 python tools/pmc_traffic.py $OUT/pmct/rd $OUT/pmct/wr 3 ${BVC_BATCH:-256} $OUT/traffic_b${BVC_BATCH:-256}.json
            find $OUT/pmct -name "*.csv" -size +5M -delete ;;
     profdefault) rm -rf $OUT/profd; cd /tmp
            run profdefault 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/profd -- python3 $R/bench.py
@@ -97,7 +97,7 @@ PY
            run prof_simclr 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_simclr -- python3 $R/tools/bench_simclr.py --vit
            cd $R; find $OUT/prof_simclr -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/kernel_stats_simclr_vitb.csv
            find $OUT/prof_simclr -name "*kernel_trace.csv" -delete ;;
-    table) run table 60 python tools/roofline_table.py $OUT/kernel_stats.csv $OUT/traffic_b${BVC_BATCH:-16}.json 7 $OUT/roofline_table_b${BVC_BATCH:-16}.txt ;;
+    table) run table 60 python tools/roofline_table.py $OUT/kernel_stats.csv $OUT/traffic_b${BVC_BATCH:-256}.json 7 $OUT/roofline_table_b${BVC_BATCH:-256}.txt ;;
     pmc_attn) rm -rf $OUT/pmc; cd /tmp
            run pmc_attn1 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d $OUT/pmc/a -- python3 $R/tools/attn_only.py
            run pmc_attn2 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS --output-format csv -d $OUT/pmc/b -- python3 $R/tools/attn_only.py

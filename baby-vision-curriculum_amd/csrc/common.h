@@ -40,25 +40,44 @@ __device__ __forceinline__ float wave_max(float v) {
 // erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, far below the bf16 rounding of the result): one v_rcp, one
 // v_exp and five FMAs instead of libm erff's ~40 VALU - the GELU epilogues were doubling the fc1 / dX-fc2 GEMMs.
 // gelu and gelu' share the exponential: with z = x / sqrt(2),  exp(-z^2) = exp(-x^2 / 2).
-struct GeluParts { float erf_abs, e; };   // erf(|z|) and exp(-x^2/2)
-__device__ __forceinline__ GeluParts gelu_parts(float x) {
-    const float az = fabsf(x) * 0.70710678118654752f;
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, az, 1.0f));
-    float p = fmaf(1.061405429f, t, -1.453152027f);
-    p = fmaf(p, t, 1.421413741f);
-    p = fmaf(p, t, -0.284496736f);
-    p = fmaf(p, t, 0.254829592f);
-    p *= t;
-    const float e = __builtin_amdgcn_exp2f(x * x * -0.72134752044448170f);   // exp(-x^2/2) = 2^(-x^2/2 * log2 e)
-    return GeluParts{fmaf(-p, e, 1.0f), e};
+// Two elements at a time: the polynomial, the squares and the final combinations are v_pk_fma_f32 / v_pk_mul_f32 (one issue for
+// two elements), only the reciprocal and the exponential stay scalar - 18 instructions per PAIR instead of ~16 per element.
+// The GELU epilogues of the decoder's K = 384 products cost as much as their whole K loop (profiles/r02_c_gemm8_store_cost.txt).
+// gelu(x) = 0.5 (x + |x| erf(|x| / sqrt 2)) (x erf(x / sqrt 2) is even), gelu'(x) = 0.5 (1 + erf(x / sqrt 2)) + x exp(-x^2/2) / sqrt(2 pi).
+struct GeluParts2 { f32x2 erf_abs, e, ax; };   // erf(|z|), exp(-x^2/2), |x|
+__device__ __forceinline__ GeluParts2 gelu_parts2(f32x2 x) {
+    GeluParts2 g;
+    g.ax.x = __builtin_fabsf(x.x); g.ax.y = __builtin_fabsf(x.y);
+    const f32x2 az = g.ax * 0.70710678118654752f;
+    const f32x2 d = __builtin_elementwise_fma(az, f32x2{0.3275911f, 0.3275911f}, f32x2{1.0f, 1.0f});
+    f32x2 t;
+    t.x = __builtin_amdgcn_rcpf(d.x); t.y = __builtin_amdgcn_rcpf(d.y);
+    f32x2 p = __builtin_elementwise_fma(t, f32x2{1.061405429f, 1.061405429f}, f32x2{-1.453152027f, -1.453152027f});
+    p = __builtin_elementwise_fma(p, t, f32x2{1.421413741f, 1.421413741f});
+    p = __builtin_elementwise_fma(p, t, f32x2{-0.284496736f, -0.284496736f});
+    p = __builtin_elementwise_fma(p, t, f32x2{0.254829592f, 0.254829592f});
+    p = p * t;
+    const f32x2 xx = x * x * -0.72134752044448170f;      // exp(-x^2/2) = 2^(-x^2/2 * log2 e)
+    g.e.x = __builtin_amdgcn_exp2f(xx.x); g.e.y = __builtin_amdgcn_exp2f(xx.y);
+    g.erf_abs = __builtin_elementwise_fma(-p, g.e, f32x2{1.0f, 1.0f});
+    return g;
 }
-__device__ __forceinline__ float gelu_f(float x) {
-    const GeluParts g = gelu_parts(x);
-    return 0.5f * x * (1.0f + copysignf(g.erf_abs, x));
+__device__ __forceinline__ f32x2 gelu2(f32x2 x) {
+    const GeluParts2 g = gelu_parts2(x);
+    return __builtin_elementwise_fma(g.ax, g.erf_abs, x) * 0.5f;
 }
-__device__ __forceinline__ float dgelu_f(float x) {
-    const GeluParts g = gelu_parts(x);
-    return fmaf(x * 0.39894228040143268f, g.e, 0.5f * (1.0f + copysignf(g.erf_abs, x)));
+__device__ __forceinline__ f32x2 dgelu2(f32x2 x) {
+    const GeluParts2 g = gelu_parts2(x);
+    f32x2 s;
+    s.x = copysignf(g.erf_abs.x, x.x); s.y = copysignf(g.erf_abs.y, x.y);
+    const f32x2 phi = __builtin_elementwise_fma(s, f32x2{0.5f, 0.5f}, f32x2{0.5f, 0.5f});
+    return __builtin_elementwise_fma(x * 0.39894228040143268f, g.e, phi);
+}
+// in place on an array of 2n floats
+template <int N2>
+__device__ __forceinline__ void gelu_inplace(float (&v)[N2]) {
+#pragma unroll
+    for (int e = 0; e < N2; e += 2) { const f32x2 r = gelu2(f32x2{v[e], v[e + 1]}); v[e] = r.x; v[e + 1] = r.y; }
 }
 
 // buffer resource over [base, base+bytes): out-of-range lanes of a buffer load return 0

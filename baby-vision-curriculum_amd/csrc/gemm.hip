@@ -323,7 +323,8 @@ __global__ __launch_bounds__(256, LB) void gemm_kernel(const GemmGroup g) {
                     store_bf16(p.C, idx, v);
                     float a[8];
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) a[e] = gelu_f(v[e]);
+                    for (int e = 0; e < 8; ++e) a[e] = v[e];
+                    gelu_inplace(a);
                     store_bf16(p.C2, idx, a);
                 } break;
                 case EPI_RESID: {
@@ -358,8 +359,9 @@ __global__ __launch_bounds__(256, LB) void gemm_kernel(const GemmGroup g) {
                                            __float_as_uint(side0[it][3])};
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        v[2 * e] *= dgelu_f(__uint_as_float(w[e] << 16));
-                        v[2 * e + 1] *= dgelu_f(__uint_as_float(w[e] & 0xffff0000u));
+                        const f32x2 dg = dgelu2(f32x2{__uint_as_float(w[e] << 16), __uint_as_float(w[e] & 0xffff0000u)});
+                        v[2 * e] *= dg.x;
+                        v[2 * e + 1] *= dg.y;
                     }
                     store_bf16(p.C, idx, v);
                 } break;

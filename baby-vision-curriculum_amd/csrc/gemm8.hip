@@ -439,7 +439,7 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const GemmGroup g, const 
                 const int nb = n0 + wn * WN + 16 * j + 4 * q4;            // < N rounded up to the tile: inside the LDS copy
                 bj[j] = *reinterpret_cast<const AS3 f32x4*>(lbias + nb);
             }
-            const bool gelu2 = epi == EPI_GELU;
+            const bool two_out = epi == EPI_GELU;
             const bool relu = epi == EPI_RELU;
             // this lane's 8 columns after the swap: tile 2 jp + (q4 & 1), columns 8 (q4 >> 1) .. + 7
             const int ncol = n0 + wn * WN + 16 * (q4 & 1) + 8 * (q4 >> 1);
@@ -466,14 +466,17 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const GemmGroup g, const 
                         __builtin_amdgcn_raw_buffer_store_b128(u32x4{s0[0], s1[0], s0[1], s1[1]}, r, o, 0, 0);
                     };
                     emit(rc);
-                    if (gelu2) {
+                    if (two_out) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) { va[e] = gelu_f(va[e]); vb[e] = gelu_f(vb[e]); }
+                        for (int e = 0; e < 4; e += 2) {
+                            const f32x2 ga = gelu2(f32x2{va[e], va[e + 1]}), gb = gelu2(f32x2{vb[e], vb[e + 1]});
+                            va[e] = ga.x; va[e + 1] = ga.y; vb[e] = gb.x; vb[e + 1] = gb.y;
+                        }
                         emit(rc2);
                     }
                 }
             }
-            nstores = gelu2 ? 2 * NSIDE : NSIDE;
+            nstores = two_out ? 2 * NSIDE : NSIDE;
         } else if (EC == 2 && atomic) {
             // split-K: f32 atomics, one dword per lane, whole contiguous rows per wave-instruction (256 B / two 128-B rows: the shape
             // the memory-side atomic units take at full rate), through a buffer descriptor (32-bit offsets, dropped when out of range)
@@ -579,8 +582,9 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const GemmGroup g, const 
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
                                 const uint32_t w = __float_as_uint(side0[c][e]);
-                                v[2 * e] *= dgelu_f(__uint_as_float(w << 16));
-                                v[2 * e + 1] *= dgelu_f(__uint_as_float(w & 0xffff0000u));
+                                const f32x2 dg = dgelu2(f32x2{__uint_as_float(w << 16), __uint_as_float(w & 0xffff0000u)});
+                                v[2 * e] *= dg.x;
+                                v[2 * e + 1] *= dg.y;
                             }
                         } else {     // EPI_DRELU: aux = the forward ReLU output, the gradient passes where it was positive
 #pragma unroll

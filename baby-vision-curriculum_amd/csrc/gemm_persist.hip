@@ -256,7 +256,8 @@ __global__ __launch_bounds__(256, 2) void gemm_persist_kernel(const GemmGroup g)
                         store_bf16(p.C, v, false);
                         float a[8];
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) a[e] = gelu_f(v[e]);
+                        for (int e = 0; e < 8; ++e) a[e] = v[e];
+                        gelu_inplace(a);
                         store_bf16(p.C2, a, true);
                     } break;
                     case EPI_RESID: {
@@ -270,8 +271,9 @@ __global__ __launch_bounds__(256, 2) void gemm_persist_kernel(const GemmGroup g)
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             const uint32_t w = __float_as_uint(side0[c][e]);
-                            v[2 * e] *= dgelu_f(__uint_as_float(w << 16));
-                            v[2 * e + 1] *= dgelu_f(__uint_as_float(w & 0xffff0000u));
+                            const f32x2 dg = dgelu2(f32x2{__uint_as_float(w << 16), __uint_as_float(w & 0xffff0000u)});
+                            v[2 * e] *= dg.x;
+                            v[2 * e + 1] *= dg.y;
                         }
                         store_bf16(p.C, v, false);
                     } break;

@@ -160,7 +160,8 @@ def main():
                          "instead of re-using clips resident in HBM; reported beside the resident-input number, never as `value`")
     args = ap.parse_args()
 
-    if args.gpus > 1 and "RANK" not in os.environ:
+    # BVC_FORCE_LAUNCH=1: take the launcher path for one rank too (rehearses parent -> child -> RCCL on a one-GPU box)
+    if (args.gpus > 1 or os.environ.get("BVC_FORCE_LAUNCH")) and "RANK" not in os.environ:
         # plain `python bench.py --gpus N`: become the launcher (as the reference's __main__ does with mp.spawn,
         # pretrain_videomae.py:509-513).  Nothing in this process has touched the GPU; N fresh interpreters run the ranks.
         sys.exit(load_launcher().spawn_ranks([os.path.abspath(__file__), *sys.argv[1:]], args.gpus))

@@ -551,8 +551,9 @@ int launch_gemm8(const GemmGroup& g, GemmLayout layout, int bn, hipStream_t stre
 // same-process A/Bs of every product of the step at 16, 64 and 256 clips (profiles/r02_e_gemm8_ab_b{16,64,256}.txt, tools/gemm8_ab.py):
 // its K loop runs ~1.2 PFLOP/s against ~0.8 for the 128 x 128 kernels, but it is ONE workgroup per CU - a launch needs about two
 // full rounds of tiles and ~45 GFLOP to amortise prologue and tail, and an epilogue is not hidden by a second resident workgroup:
-//   * 256 x 256: plain bf16-output epilogues (BF16 / GELU / RELU) with >= 448 tiles whose last column tile is at least 85 % full
-//     (encoder qkv / fc1 / dX at >= 64 clips, decoder qkv / fc1: -20 ... -27 % at 256 clips, -5 ... -10 % at 64);
+//   * 256 x 256: plain bf16-output epilogues (BF16 / GELU / RELU) and f32-output ones (residual, positional, plain) with >= 448
+//     tiles whose last column tile is at least 85 % full (encoder qkv / fc1 / dX at >= 64 clips, decoder qkv / fc1: -20 ... -27 %
+//     at 256 clips, -5 ... -10 % at 64; encoder proj / fc2 at 256 clips);
 //   * 256 x 128: input-gradient products (NN, bf16 out) and residual products (f32 + residual) with K >= 1024 and >= 224 tiles
 //     when the 256-wide tile would be half empty (decoder N = 384: dX-fc1, dX-qkv, fc2);
 //   * never: GELU' / ReLU' (their side-input epilogue still parks through LDS and drains the prefetch: no gain measured),
@@ -564,12 +565,14 @@ static int pick_gemm8(const GemmProblem* probs, int nprob, GemmLayout layout) {
     const GemmProblem& p = probs[0];
     if (p.split_k != 1 || p.K % 64 != 0) return -1;
     const bool bf = p.epi == EPI_BF16 || p.epi == EPI_GELU || p.epi == EPI_RELU;
-    const bool resid = p.epi == EPI_RESID && layout == GEMM_NT;
+    const bool resid = (p.epi == EPI_RESID || p.epi == EPI_POS || p.epi == EPI_F32) && layout == GEMM_NT;    // f32 out (+ f32 side input)
     if (!bf && !resid) return -1;
     if (2.0 * p.M * p.N * p.K < 45e9) return -1;
     const int tm = (p.M + 255) / 256, tn256 = (p.N + 255) / 256, tn128 = (p.N + 127) / 128;
     const bool full256 = (double)p.N >= 0.85 * 256.0 * tn256;
-    if (bf && full256 && tm * tn256 >= 448) return 10;
+    // (the f32 class runs its side inputs in four passes on 256 x 256 tiles: encoder proj / fc2 / patch embedding at 256 clips
+    //  -10 / -21 / -17 %, a loss below 448 tiles - profiles/r02_g_gemm8_resid_ab.txt)
+    if (full256 && tm * tn256 >= 448) return 10;
     if ((bf ? layout == GEMM_NN : p.N <= 384) && p.K >= 1024 && tm * tn128 >= (resid ? 1024 : 224)) return 11;
     return -1;
 }

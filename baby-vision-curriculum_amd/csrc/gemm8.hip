@@ -513,13 +513,22 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const GemmGroup g, const 
                 bias0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rbias, ob, 0, 0));
                 bias1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rbias, ob, 16, 0));
             }
-            f32x4 side0[(EC == 1 || EC == 3) ? NSIDE : 1], side1[(EC == 1) ? NSIDE : 1];
+            // Side inputs of the whole unit would be 128 registers for the f32 class on 256 x 256 tiles: that combination runs in
+            // NP = 4 passes of 2 row rounds each (loads, drain, stores, loads, ...; two passes still spilled inside the K loop);
+            // every later pass's wait also waits for the previous pass's stores (three store round trips per unit - acceptable
+            // only for the long-K products it is selected for).
+            constexpr int NP = (EC == 1 && BN == 256) ? 4 : 1;
+            constexpr int NSP = NSIDE / NP, TMP = TM / NP;
+            f32x4 side0[(EC == 1 || EC == 3) ? NSP : 1], side1[(EC == 1) ? NSP : 1];
+            float sumsq = 0.f;
+#pragma unroll
+            for (int pass = 0; pass < NP; ++pass) {
             if constexpr (EC == 3) {
                 const __amdgpu_buffer_rsrc_t raux = make_rsrc(p.aux, kDrop);
                 const int ldaux = p.ldaux;
 #pragma unroll
-                for (int c = 0; c < NSIDE; ++c) {
-                    const int m = m0 + wm * 128 + 16 * (c / U) + (((c % U) * 64 + lane) / CPR);
+                for (int c = 0; c < NSP; ++c) {
+                    const int m = m0 + wm * 128 + 16 * ((c + pass * NSP) / U) + ((((c + pass * NSP) % U) * 64 + lane) / CPR);
                     side0[c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(raux, offs(m, ldaux, 2), 0, 0));
                 }
             } else if constexpr (EC == 1) {
@@ -529,8 +538,8 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const GemmGroup g, const 
                 const __amdgpu_buffer_rsrc_t rside = make_rsrc(sbase, side_f32 ? kDrop : 0u);
                 const __amdgpu_buffer_rsrc_t rtok = make_rsrc(p.rowtok, by_tok ? kDrop : 0u);
 #pragma unroll
-                for (int c = 0; c < NSIDE; ++c) {
-                    const int m = m0 + wm * 128 + 16 * (c / U) + (((c % U) * 64 + lane) / CPR);
+                for (int c = 0; c < NSP; ++c) {
+                    const int m = m0 + wm * 128 + 16 * ((c + pass * NSP) / U) + ((((c + pass * NSP) % U) * 64 + lane) / CPR);
                     uint32_t o = offs(m, ldc, 4);
                     if (by_tok) {
                         const int tok = __builtin_amdgcn_raw_buffer_load_b32(rtok, m < Mrows ? (uint32_t)m * 4u : kDrop, 0, 0);
@@ -546,15 +555,14 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const GemmGroup g, const 
             asm volatile("" : "+v"(bias0), "+v"(bias1));
             if constexpr (EC == 1 || EC == 3) {
 #pragma unroll
-                for (int c = 0; c < NSIDE; ++c) asm volatile("" : "+v"(side0[c]));
+                for (int c = 0; c < NSP; ++c) asm volatile("" : "+v"(side0[c]));
             }
             if constexpr (EC == 1) {
 #pragma unroll
-                for (int c = 0; c < NSIDE; ++c) asm volatile("" : "+v"(side1[c]));
+                for (int c = 0; c < NSP; ++c) asm volatile("" : "+v"(side1[c]));
             }
-            float sumsq = 0.f;
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
+            for (int i = pass * TMP; i < (pass + 1) * TMP; ++i) {
                 park(i);
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
@@ -562,7 +570,7 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const GemmGroup g, const 
                     const int m = m0 + wm * 128 + 16 * i + row;
                     const f32x4 lo = *reinterpret_cast<const AS3 f32x4*>(wl + row * (WN * 4) + (((2 * cc) ^ (row & (UNITS - 1))) << 4));
                     const f32x4 hi = *reinterpret_cast<const AS3 f32x4*>(wl + row * (WN * 4) + (((2 * cc + 1) ^ (row & (UNITS - 1))) << 4));
-                    const int c = U * i + u;
+                    const int c = U * i + u - pass * NSP;
                     const bool ok = m < Mrows && ncol_ok;
                     float v[8] = {lo[0] * alpha + bias0[0], lo[1] * alpha + bias0[1], lo[2] * alpha + bias0[2], lo[3] * alpha + bias0[3],
                                   hi[0] * alpha + bias1[0], hi[1] * alpha + bias1[1], hi[2] * alpha + bias1[2], hi[3] * alpha + bias1[3]};
@@ -623,6 +631,7 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const GemmGroup g, const 
                     }
                 }
             }
+            }   // pass
             if (EC == 1 && epi == EPI_LOSS) {
                 // deterministic per-tile partial of sum (logit - label)^2: every wave leaves its sum in the first word of its own
                 // parking rows, one lane folds the eight in a fixed order.  The wave rows run one barrier apart, so the fold
@@ -709,8 +718,7 @@ int launch_gemm8(const GemmGroup& g, GemmLayout layout, int bn, hipStream_t stre
         if (layout != GEMM_TN && (p.split_k != 1 || p.K % 64 != 0)) return 1;
         if (layout == GEMM_TN && p.split_k > 1 && p.epi != EPI_F32) return 1;
         if (p.rowsum && layout != GEMM_TN) return 1;
-        // the f32-side epilogues keep 8 floats of side input per chunk in registers: 256 x 128 tiles only
-        if (c == 1 && bn != 128) return 1;
+        // the f32-side epilogues keep 8 floats of side input per chunk in registers: one pass on 256 x 128 tiles, two on 256 x 256
         // class 0 keeps the whole (tile-padded) bias vector in LDS (32 KiB): one problem, N up to 8192
         if (c == 0 && (g.nprob != 1 || (size_t)((p.N + bn - 1) / bn) * bn * 4 > (size_t)32768)) return 1;
     }
@@ -719,11 +727,11 @@ int launch_gemm8(const GemmGroup& g, GemmLayout layout, int bn, hipStream_t stre
     if (layout == GEMM_NT) {
         if (ec == 0) { if (bn == 256) BVC_G8(256, false, false, 0); else BVC_G8(128, false, false, 0); }
         if (ec == 3) { if (bn == 256) BVC_G8(256, false, false, 3); else BVC_G8(128, false, false, 3); }
-        if (ec == 1) BVC_G8(128, false, false, 1);
+        if (ec == 1) { if (bn == 256) BVC_G8(256, false, false, 1); else BVC_G8(128, false, false, 1); }
     } else if (layout == GEMM_NN) {
         if (ec == 0) { if (bn == 256) BVC_G8(256, false, true, 0); else BVC_G8(128, false, true, 0); }
         if (ec == 3) { if (bn == 256) BVC_G8(256, false, true, 3); else BVC_G8(128, false, true, 3); }
-        if (ec == 1) BVC_G8(128, false, true, 1);
+        if (ec == 1) { if (bn == 256) BVC_G8(256, false, true, 1); else BVC_G8(128, false, true, 1); }
     } else {
         if (bn == 256) BVC_G8(256, true, true, 2); else BVC_G8(128, true, true, 2);
     }

@@ -270,7 +270,22 @@ def _entry(body, rank, world, port, q):
         q.put((rank, "error", traceback.format_exc()))
 
 
-def _run(body, world=2):
+RENDEZVOUS_ERRORS = ("Address already in use", "Connection refused", "Connection reset", "Broken pipe", "timed out", "Timed out", "EADDRINUSE")
+
+
+def _run(body, world=2, attempts=2):
+    """One retry with a fresh port when the failure is in the TCP rendezvous (the OS-assigned port can be taken between its probe and
+    rank 0's bind on a busy host); anything else fails at once with the ranks' tracebacks."""
+    for attempt in range(attempts):
+        try:
+            return _run_once(body, world)
+        except AssertionError as e:
+            if attempt + 1 < attempts and any(k in str(e) for k in RENDEZVOUS_ERRORS):
+                continue
+            raise
+
+
+def _run_once(body, world=2):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()

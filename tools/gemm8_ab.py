@@ -57,8 +57,6 @@ def main():
             kw["bias"] = torch.randn(N, device=dev)
         d = G.gemm_desc(A, B, M, N, K, G.EPI[epi], C, **kw)
         tiles = [-1, 10, 11]
-        if f32:
-            tiles = [-1, 11]
         times = {t: [] for t in tiles}
         iters = 5
         for t in tiles:

@@ -308,7 +308,7 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const GemmGroup g, const 
                         else if (after_epi == 2 * NSIDE) wait_vmcnt<W1 + 2 * NSIDE>();
                     }
                     if constexpr (q == 3) wait_vmcnt<W3>();
-                    asm volatile("s_barrier\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+                    asm volatile("s_barrier" ::: "memory");   // fragment reads are builtins: hipcc places counted lgkmcnt waits in front of the MFMAs that use them
                     __builtin_amdgcn_sched_barrier(0);
                     __builtin_amdgcn_s_setprio(1);
                     constexpr int NM = 4 * TN;       // MFMAs of the phase: the two LDS-DMA loads go after the first and the second quarter
@@ -349,7 +349,7 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const GemmGroup g, const 
                         else if (after_epi == 2 * NSIDE) wait_vmcnt<W1 + 2 * NSIDE>();
                     }
                     if constexpr (q == 3) wait_vmcnt<W3>();
-                    asm volatile("s_barrier\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+                    asm volatile("s_barrier" ::: "memory");   // fragment reads are builtins: hipcc places counted lgkmcnt waits in front of the MFMAs that use them
                     __builtin_amdgcn_sched_barrier(0);
                     __builtin_amdgcn_s_setprio(1);
                     constexpr int NM = 4 * TN;

@@ -96,6 +96,13 @@ __device__ __forceinline__ void glds16(__amdgpu_buffer_rsrc_t rs, uint32_t voff,
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(voff), "s"(rs), "s"(lds_addr) : "memory");
 }
+// the same piece with a wave-uniform byte offset in an SGPR (soffset) added to the per-lane one: one per-lane address
+// register then serves several images of the same rows (the K and the V columns of a qkv row, attention.hip)
+__device__ __forceinline__ void glds16s(__amdgpu_buffer_rsrc_t rs, uint32_t voff, uint32_t soff, uint32_t lds_addr) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(rs), "s"(soff), "s"(lds_addr) : "memory");
+}
 // the 4-byte form (64 lanes x 4 B -> 256 B of LDS): per-row statistics next to an operand tile
 __device__ __forceinline__ void glds4(__amdgpu_buffer_rsrc_t rs, uint32_t voff, uint32_t lds_addr) {
     uint32_t keep;

@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from tests import gpu_util as G
 L = G.L
-B, N, H, HD = 16, 1568, 6, 64
+B, N, H, HD = int(os.environ.get("BVC_BATCH", "64")), 1568, 6, 64
 D = HD * H
 qkv = G.bf16_randn(B * N, 3 * D)
 ctx = torch.zeros(B * N, D, device="cuda", dtype=torch.bfloat16)

@@ -98,10 +98,6 @@ PY
            cd $R; find $OUT/prof_simclr -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/kernel_stats_simclr_vitb.csv
            find $OUT/prof_simclr -name "*kernel_trace.csv" -delete ;;
     table) run table 60 python tools/roofline_table.py $OUT/kernel_stats.csv $OUT/traffic_b${BVC_BATCH:-256}.json 7 $OUT/roofline_table_b${BVC_BATCH:-256}.txt ;;
-    pmc_attn) rm -rf $OUT/pmc; cd /tmp
-           run pmc_attn1 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d $OUT/pmc/a -- python3 $R/tools/attn_only.py
-           run pmc_attn2 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS --output-format csv -d $OUT/pmc/b -- python3 $R/tools/attn_only.py
-           cd $R ;;
     pmc_gemm) rm -rf $OUT/pmcg; cd /tmp
            run pmc_gemm1 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA --output-format csv -d $OUT/pmcg/a -- python3 $R/tools/gemm_only.py
            run pmc_gemm2 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_SALU SQ_INST_CYCLES_VMEM --output-format csv -d $OUT/pmcg/b -- python3 $R/tools/gemm_only.py
@@ -118,6 +114,18 @@ PY
              find $OUT/pmcg8/$c -name "*.csv" -size +2M -delete
            done
            unset BVC_G8_CASE; cd $R; cat $OUT/pmc_g8_*.txt ;;
+    pmc_attn) rm -rf $OUT/pmcattn; cd /tmp
+           run pmc_attn_a 200 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA --output-format csv -d $OUT/pmcattn/a -- python3 $R/tools/attn_only.py
+           run pmc_attn_b 200 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_SALU SQ_INST_CYCLES_VMEM --output-format csv -d $OUT/pmcattn/b -- python3 $R/tools/attn_only.py
+           run pmc_attn_c 200 rocprofv3 --kernel-trace --pmc SQ_INSTS_VMEM SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_VMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_SCA GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmcattn/c -- python3 $R/tools/attn_only.py
+           python3 $R/tools/pmc_summary.py $OUT/pmcattn/a $OUT/pmcattn/b $OUT/pmc_attn.txt > /dev/null
+           python3 $R/tools/pmc_summary.py $OUT/pmcattn/c $OUT/pmcattn/c $OUT/pmc_attn_c.txt > /dev/null
+           find $OUT/pmcattn -name "*.csv" -size +2M -delete
+           cd $R; cat $OUT/pmc_attn.txt $OUT/pmc_attn_c.txt ;;
+    attnab) for v in $BVC_VARIANTS; do
+             if [ "$v" = "prod" ]; then unset BVC_LIB_PATH; else export BVC_LIB_PATH=$R/baby-vision-curriculum_amd/libbvc_hip_$v.so; fi
+             run attnab_$v 200 python tools/attn_ab.py
+           done; unset BVC_LIB_PATH ;;
     *) echo "unknown step $step" ;;
   esac
 done

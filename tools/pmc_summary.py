@@ -5,7 +5,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for d in sys.argv[1:3]:
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            if "gemm" in r["Kernel_Name"]:
+            if "gemm" in r["Kernel_Name"] or "attn" in r["Kernel_Name"]:
                 agg[(r["Kernel_Name"].split("(")[0].replace("void ", ""), r["Grid_Size"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
 lines = []
 for (k, grid), v in sorted(agg.items()):

@@ -17,12 +17,13 @@
 // round-trips through LDS.  dS/dP are recomputed in the dQ kernel (7 instead of 5 products) in
 // exchange for a deterministic, atomic-free dQ.
 //
-// What bounds them (rocprofv3 --pmc at the decoder shape, 64 clips: profiles/r02_h_attention_single_wave.txt): with 32 rows per
-// wave every K / V (Q / dO) fragment read from LDS feeds ONE 32 x 32 score block - 16 LDS instructions (12 KiB) per 12 MFMAs in dQ -
-// and LDS returns 64 B per cycle per CU for all four SIMDs: SQ_LDS_IDX_ACTIVE is 0.7-0.8 of the kernel's cycles while the MFMA pipe
-// is 0.35-0.41 busy at the 2.1 GHz the chip holds.  A third wave per SIMD (dQ fits 168 registers) changes nothing (+-1 %).
-// The alternative that removes the LDS bound - one wave = 96 rows with the whole register file, software-pipelined by hand - was
-// built and measured (experiment section below): 3-4 % at the decoder shape, nothing elsewhere, so it is not the product path.
+// What bounds them (rocprofv3 --pmc at the decoder shape, 64 clips: profiles/r02_h_attention_single_wave.txt): the MFMA pipe is
+// 0.39-0.47 busy at the ~2.1 GHz the chip holds, no LDS bank conflicts, LDS demand highest in dK/dV.  With 32 rows per wave every
+// K / V (Q / dO) fragment read from LDS feeds ONE 32 x 32 score block (dQ: 12 KiB per 12 MFMAs).  A third wave per SIMD (dQ fits
+// 168 registers) changes nothing (+-1 %).  The alternative - one wave = 96 rows with the whole register file, a third of the LDS reads
+// per MFMA, software-pipelined by hand - was built and measured (experiment section below): 3-4 % at the decoder shape, nothing
+// elsewhere; its ablated MFMA-only stream runs at 0.55-0.6 of the nominal rate, the same ceiling the 8192^3 GEMM shows, so these
+// kernels are within 1.2-1.3x of what the chip sustains on random operands and the experiment is not the product path.
 // The first version was VALU-issue bound (rocprofv3: 45 VALU per MFMA), so the loops are written to keep the VALU count down:
 //   * __launch_bounds__(256, 2): <= 256 registers makes hipcc pick the VGPR form of the MFMA, so
 //     accumulators are scaled / exponentiated in place (no v_accvgpr_read/write round trips);
@@ -405,10 +406,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
 // shape, equal at N = 160, 15 % slower at head_dim 32 - not worth its inline-asm hazard contract, so the 32-row kernels stay.
 #ifdef BVC_EXPERIMENTS
 // The kernels above give every wave 32 rows and read each K / V (or Q / dO) fragment from LDS for ONE 32 x 32 score block:
-// 16 LDS instructions (12 KiB) per 12 MFMAs in dQ.  LDS returns 64 B per cycle per CU to all four SIMDs, so those reads take
-// 2x the MFMA time of the same block: rocprofv3 shows the LDS unit 70-80 % busy and the MFMA pipe at 0.35-0.4
-// (profiles/r02_h_pmc_attention.txt) - the kernels are LDS-bandwidth bound, not issue bound, and a third wave per SIMD buys nothing.
-// The kernels below give ONE wave NB = 3 blocks of 32 rows (96 queries, or 96 keys) and the whole 512-register file
+// 16 LDS instructions (12 KiB) per 12 MFMAs in dQ (counters: profiles/r02_h_attention_single_wave.txt).
+// The kernel below gives ONE wave NB = 3 blocks of 32 rows (96 queries) and the whole 512-register file
 // (one wave per SIMD, four single-wave workgroups per CU): every fragment read from LDS feeds NB MFMAs, the NB blocks are
 // independent dependency chains (one block's softmax arithmetic runs beside another block's MFMAs), and with one wave per
 // workgroup there is no barrier at all: the K / V (Q / dO) stream is a private 4-stage ring of 32-row tiles filled by LDS-DMA

@@ -143,6 +143,18 @@ SYMBOLS = {
     "bvc_op_mask_index": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "bvc_op_gather_patches": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "bvc_op_pixel_labels": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "bvc_comm_unique_id": (c_int, [c_void_p]),
+    "bvc_comm_init": (c_int, [c_int, c_int, c_void_p, ctypes.POINTER(c_void_p)]),
+    "bvc_comm_destroy": (c_int, [c_void_p]),
+    "bvc_comm_stream": (c_void_p, [c_void_p]),
+    "bvc_comm_rank": (c_int, [c_void_p]),
+    "bvc_comm_world": (c_int, [c_void_p]),
+    "bvc_comm_library": (c_char_p, []),
+    "bvc_allreduce_bucket": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    "bvc_comm_wait": (c_int, [c_void_p, c_void_p]),
+    "bvc_allgather": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "bvc_allreduce": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    "bvc_broadcast": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),
 }
 
 _lib = None

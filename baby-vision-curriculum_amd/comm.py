@@ -1,0 +1,128 @@
+"""The library's RCCL communicator (include/bvc.h "communication") for the ranks of a torch.distributed job.
+
+The reference's entry points create the process group themselves (dist.init_process_group("nccl", ...),
+pretraining/generative/pretrain_videomae.py:87-90) and every collective of the step then goes through it.  Here the step's
+collectives - gradient buckets during backward, the SimCLR embedding all-gather - run on a communicator the library owns
+(its own communication stream and event fences, no Python between a bucket's last kernel and its all-reduce); the process
+group the script initialised is used once, to hand rank 0's 128-byte RCCL id to the other ranks, and for a one-off
+cross-check of the new communicator against it.
+
+`get(device)` returns the communicator of this process, or None when the job is not on RCCL (gloo on CPU, no process group):
+callers then stay on torch.distributed.  BVC_COMM=torch forces that too (A/B of the two paths on one box).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import warnings
+
+import torch
+import torch.distributed as dist
+
+from . import _lib
+
+_comm = None
+_tried = False
+
+
+class Communicator:
+    def __init__(self, handle, rank, world, device):
+        self.handle, self.rank, self.world, self.device = handle, rank, world, device
+
+    @property
+    def library(self):
+        return _lib.lib().bvc_comm_library().decode()
+
+    def _stream(self):
+        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def torch_stream(self):
+        """The communication stream as a torch stream (timing events of the bucket report); owned by the library."""
+        return torch.cuda.ExternalStream(_lib.lib().bvc_comm_stream(self.handle), device=self.device)
+
+    def allreduce_bucket(self, t, average=True):
+        """In-place mean (or sum) over ranks of a contiguous f32 tensor, on the communication stream, after the kernels enqueued on
+        the current stream.  Asynchronous: `wait()` orders the current stream behind it."""
+        assert t.dtype == torch.float32 and t.is_contiguous()
+        _lib.check(_lib.lib().bvc_allreduce_bucket(self.handle, ctypes.c_void_p(t.data_ptr()), t.numel(), int(average), self._stream()),
+                   "bvc_allreduce_bucket")
+
+    def wait(self):
+        _lib.check(_lib.lib().bvc_comm_wait(self.handle, self._stream()), "bvc_comm_wait")
+
+    def allreduce(self, t, average=False):
+        assert t.dtype == torch.float32 and t.is_contiguous()
+        _lib.check(_lib.lib().bvc_allreduce(self.handle, ctypes.c_void_p(t.data_ptr()), t.numel(), int(average), self._stream()), "bvc_allreduce")
+
+    def allgather(self, src, out):
+        assert src.is_contiguous() and out.is_contiguous() and out.numel() * out.element_size() == self.world * src.numel() * src.element_size()
+        _lib.check(_lib.lib().bvc_allgather(self.handle, ctypes.c_void_p(src.data_ptr()), ctypes.c_void_p(out.data_ptr()),
+                                            src.numel() * src.element_size(), self._stream()), "bvc_allgather")
+
+    def broadcast(self, t, root=0):
+        assert t.is_contiguous()
+        _lib.check(_lib.lib().bvc_broadcast(self.handle, ctypes.c_void_p(t.data_ptr()), t.numel() * t.element_size(), int(root), self._stream()),
+                   "bvc_broadcast")
+
+    def close(self):
+        if self.handle is not None:
+            _lib.lib().bvc_comm_destroy(self.handle)
+            self.handle = None
+
+
+def _create(device):
+    rank, world = dist.get_rank(), dist.get_world_size()
+    lib = _lib.lib()
+    ident = torch.zeros(128, dtype=torch.uint8)
+    if rank == 0:
+        buf = (ctypes.c_uint8 * 128)()
+        _lib.check(lib.bvc_comm_unique_id(buf), "bvc_comm_unique_id")
+        ident = torch.tensor(list(buf), dtype=torch.uint8)
+    ident = ident.to(device)
+    dist.broadcast(ident, src=0)                        # the side channel: the script's own process group
+    raw = bytes(ident.cpu().tolist())
+    handle = ctypes.c_void_p()
+    with torch.cuda.device(device):
+        _lib.check(lib.bvc_comm_init(rank, world, ctypes.c_char_p(raw), ctypes.byref(handle)), "bvc_comm_init")
+    c = Communicator(handle, rank, world, device)
+    # cross-check against the process group before anything depends on it: mean of (rank + 1) over ranks, and an all-gather
+    probe = torch.full((1024,), float(rank + 1), device=device)
+    c.allreduce_bucket(probe, average=True)
+    c.wait()
+    ref = torch.full((1024,), float(rank + 1), device=device)
+    dist.all_reduce(ref, op=dist.ReduceOp.SUM)
+    ref /= world
+    gathered = torch.empty(world * 4, device=device)
+    c.allgather(torch.full((4,), float(rank), device=device), gathered)
+    want = torch.arange(world, device=device, dtype=torch.float32).repeat_interleave(4)
+    if not (torch.allclose(probe, ref) and torch.equal(gathered, want)):
+        c.close()
+        raise _lib.BvcError("the library's communicator disagrees with the process group on a probe all-reduce / all-gather")
+    return c
+
+
+def get(device=None):
+    """This process's communicator on `device`, created on first use; None when torch.distributed is not running on RCCL."""
+    global _comm, _tried
+    if _comm is not None or _tried:
+        return _comm
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_backend() != "nccl" or not torch.cuda.is_available():
+        return None
+    if os.environ.get("BVC_COMM", "") == "torch":
+        return None
+    _tried = True
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    try:
+        _comm = _create(device)
+    except Exception as e:   # every rank takes the same branch: the failure modes (library missing, init error) are per-machine
+        warnings.warn(f"bvc communicator unavailable ({e}); the step's collectives stay on torch.distributed")
+        _comm = None
+    return _comm
+
+
+def reset():
+    """Drop the communicator (tests; dist.destroy_process_group)."""
+    global _comm, _tried
+    if _comm is not None:
+        _comm.close()
+    _comm, _tried = None, False

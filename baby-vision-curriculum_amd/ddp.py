@@ -29,6 +29,8 @@ import torch
 import torch.distributed as dist
 import torch.nn as nn
 
+from . import comm as _comm
+
 
 def _is_flat(m):
     return hasattr(m, "flat_parameters") and hasattr(m, "flat_grads")
@@ -57,6 +59,7 @@ class DistributedDataParallel(nn.Module):
         self.force_collectives = force_collectives   # issue the collectives even with one rank (tests, one-GPU rehearsal)
         self.bucket_elems = int(bucket_cap_mb * 1024 * 1024 / 4)
         self._comm_stream = None
+        self._native = None           # the library's RCCL communicator (comm.py) when the job runs on RCCL, else torch.distributed
         self._events = []             # pre-allocated fence events, reused round robin (one per bucket in flight)
         self._ev_next = 0
         self.profile_buckets = profile_buckets
@@ -122,9 +125,32 @@ class DistributedDataParallel(nn.Module):
         self._ev_next += 1
         return ev
 
+    def _native_comm(self, device):
+        if self._native is None and self.process_group is None:
+            self._native = _comm.get(device) or False
+        return self._native or None
+
+    @property
+    def comm_backend(self):
+        """"bvc-rccl" (library communicator, include/bvc.h), "torch-nccl" or "torch-gloo" - what the buckets travel on."""
+        if self._native:
+            return "bvc-rccl"
+        return "torch-" + dist.get_backend(self.process_group)
+
     def _all_reduce_avg(self, g):
         """In-place mean over ranks of a contiguous gradient tensor, on the communication stream when it lives on a GPU."""
         if g.is_cuda:
+            nc = self._native_comm(g.device)
+            if nc is not None:        # fence, stream hop and ncclAllReduce(ncclAvg) inside the library (bvc_allreduce_bucket)
+                if self.profile_buckets:
+                    cs = nc.torch_stream()
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(torch.cuda.current_stream(g.device))   # completes with the bucket's producer kernels = the fence
+                nc.allreduce_bucket(g, average=True)
+                if self.profile_buckets:
+                    e1.record(cs)
+                    self._timed.append((g.numel() * g.element_size(), e0, e1))
+                return
             if self._comm_stream is None:
                 self._comm_stream = torch.cuda.Stream(device=g.device)
             ev = self._fence_event()
@@ -169,6 +195,8 @@ class DistributedDataParallel(nn.Module):
         st.reduced_ranges.append((lo, hi))
 
     def _join(self, device):
+        if self._native:
+            self._native.wait()
         if self._comm_stream is not None:
             torch.cuda.current_stream(device).wait_stream(self._comm_stream)
 
@@ -177,6 +205,8 @@ class DistributedDataParallel(nn.Module):
         if st.pending is not None:
             self._reduce(st, *st.pending)
             st.pending = None
+        if self._native:
+            self._native.wait()
         if self._comm_stream is not None:
             self._join(self._comm_stream.device)
         st.fresh = True

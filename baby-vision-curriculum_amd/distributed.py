@@ -11,6 +11,8 @@ With one process (or no process group) every node is the identity, so single-GPU
 import torch
 import torch.distributed as dist
 
+from . import comm as _comm
+
 
 def world():
     """(rank, size) of the default group; (0, 1) when torch.distributed is not in use."""
@@ -67,7 +69,11 @@ class AllGather(torch.autograd.Function):
             return x
         src = x.contiguous()
         out = src.new_empty((n * src.shape[0],) + tuple(src.shape[1:]))
-        dist.all_gather_into_tensor(out, src)          # one contiguous destination: no list of pieces, no cat
+        nc = _comm.get(src.device) if src.is_cuda else None
+        if nc is not None:
+            nc.allgather(src, out)                     # bvc_allgather on the current stream (include/bvc.h)
+        else:
+            dist.all_gather_into_tensor(out, src)      # one contiguous destination: no list of pieces, no cat
         return out
 
     @staticmethod
@@ -75,5 +81,10 @@ class AllGather(torch.autograd.Function):
         start, rows, n = ctx.span
         if n == 1:
             return grad_output
-        total = _reduced(grad_output, 1.0)
+        nc = _comm.get(grad_output.device) if grad_output.is_cuda and grad_output.dtype == torch.float32 else None
+        if nc is not None:
+            total = grad_output.contiguous().clone()
+            nc.allreduce(total, average=False)
+        else:
+            total = _reduced(grad_output, 1.0)
         return total.narrow(0, start, rows)

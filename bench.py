@@ -183,8 +183,9 @@ def main():
     torch.set_num_threads(min(8, host_cores()))
     if use_ddp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world)   # "nccl" is RCCL on ROCm
+        if "MASTER_PORT" not in os.environ:      # no launcher (BVC_FORCE_DDP on one GPU): an OS-assigned port, so back-to-back runs never meet in TIME_WAIT
+            os.environ["MASTER_PORT"] = str(load_launcher().free_port())
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # "nccl" is RCCL on ROCm
 
     if local_rank == 0:
         ge.build()          # one builder per node; the other ranks wait for the library
@@ -284,8 +285,10 @@ def main():
             step()
         torch.cuda.synchronize()
         rep = xmodel.bucket_report()
-        comm = {"backend": "rccl (torch.distributed nccl)", "ranks": dist.get_world_size(), "bucket_cap_mb": args.bucket_mb,
-                "buckets_last_step": rep[-1] if rep else []}
+        native = bvc.comm.get(dev)
+        comm = {"backend": ("rccl via libbvc_hip.so (bvc_allreduce_bucket): " + native.library) if xmodel.comm_backend == "bvc-rccl"
+                else "rccl via torch.distributed (nccl)",
+                "ranks": dist.get_world_size(), "bucket_cap_mb": args.bucket_mb, "buckets_last_step": rep[-1] if rep else []}
         xmodel.profile_buckets = False
     stream_info = None
     if ring is not None:

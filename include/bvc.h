@@ -272,6 +272,43 @@ int bvc_op_gather_patches(const float* clip, const int* vis_idx, void* A_bf16, i
 int bvc_op_pixel_labels(const float* clip, const int* msk_idx, float* labels, int B, int nmask, int T, int C, int H, int W,
                         int ts, int ps, int norm_pix, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Communication: one RCCL rank per process (one process per GPU), the communication stream and its event fences owned by the
+ * library.  Replaces, for this path, what the reference reaches through torch.distributed:
+ *   dist.init_process_group("nccl", rank=rank, world_size=world)      pretraining/generative/pretrain_videomae.py:87-90
+ *   DistributedDataParallel's gradient reducer                         pretrain_videomae.py:180-181,312 (bucketed all-reduce, mean)
+ *   AllReduce / AllGather autograd nodes                               pretraining/generative/ddputils.py:53-68,
+ *                                                                      pretraining/predictive/distributed.py:49-76
+ * RCCL is bound at run time (the librccl.so already mapped into the process when there is one - torch ships its own - else the
+ * loader's), so the library links without it and loads on a machine without a GPU.
+ * Rendezvous: rank 0 calls bvc_comm_unique_id and hands the 128 bytes to the other ranks by any side channel (the Python shim
+ * broadcasts them over the process group the entry script has already initialised); every rank then calls bvc_comm_init with
+ * its HIP device current.  All calls on one communicator come from the host thread that drives the step. */
+#define BVC_COMM_ID_BYTES 128
+typedef struct bvc_comm bvc_comm;
+int bvc_comm_unique_id(void* id_out_host /* BVC_COMM_ID_BYTES */);
+int bvc_comm_init(int rank, int world, const void* id_host, bvc_comm** out);
+int bvc_comm_destroy(bvc_comm* comm);
+/* the communication stream (hipStream_t), e.g. to record timing events around a bucket; owned by the communicator */
+void* bvc_comm_stream(const bvc_comm* comm);
+int bvc_comm_rank(const bvc_comm* comm);
+int bvc_comm_world(const bvc_comm* comm);
+/* path and version of the RCCL library in use (thread-local string; loads the library on first use) */
+const char* bvc_comm_library(void);
+/* One gradient bucket: in-place sum (average != 0: mean) over ranks of count f32 at buf, enqueued on the communication stream
+ * behind an event recorded on producer_stream (the stream whose kernels wrote buf).  Returns immediately: this is the call a
+ * bvc_bucket_fn makes while the rest of backward is still being enqueued. */
+int bvc_allreduce_bucket(bvc_comm* comm, float* buf_dev, int64_t count, int average, void* producer_stream);
+/* `stream` waits (event, no host block) for every bucket enqueued so far: end of backward, before the optimiser reads the gradients */
+int bvc_comm_wait(bvc_comm* comm, void* stream);
+/* Collectives that run ON the caller's stream (their result is consumed next):
+ *   allgather  recv[r * bytes_per_rank ...] = rank r's send buffer           (SimCLR global-batch negatives, forward)
+ *   allreduce  in-place sum / mean of count f32                              (its backward; the loss scalar)
+ *   broadcast  root's buffer to every rank                                   (module-state sync at wrap time) */
+int bvc_allgather(bvc_comm* comm, const void* send_dev, void* recv_dev, int64_t bytes_per_rank, void* stream);
+int bvc_allreduce(bvc_comm* comm, float* buf_dev, int64_t count, int average, void* stream);
+int bvc_broadcast(bvc_comm* comm, void* buf_dev, int64_t bytes, int root, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

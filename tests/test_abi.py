@@ -100,3 +100,23 @@ def test_allreduce_and_grad_logger_single_process(bvc):
     w = torch.nn.Parameter(torch.ones(2, 2)); w.grad = torch.full((2, 2), 2.0)
     s = bvc.grad_logger([("decoder.head.weight", w), ("other", w)])
     assert s.dec_last_layer == pytest.approx(4.0) and s.enc_first_layer == 0.0
+
+
+def test_comm_group_binds_rccl_at_run_time_and_rejects_bad_arguments(bvc):
+    """include/bvc.h "communication" without a GPU: the library carries no link-time RCCL dependency, finds the librccl.so this
+    process already maps (torch's) and reports argument errors through the usual status + message channel."""
+    import ctypes
+    import subprocess
+    lib = bvc._lib.lib()
+    needed = subprocess.run(["readelf", "-d", bvc._lib.LIB_PATH], capture_output=True, text=True).stdout
+    assert "rccl" not in needed.lower()
+    where = lib.bvc_comm_library().decode()
+    assert "librccl.so" in where and "version" in where
+    h = ctypes.c_void_p()
+    assert lib.bvc_comm_init(0, 1, None, ctypes.byref(h)) != 0 and b"null argument" in lib.bvc_last_error()
+    ident = (ctypes.c_uint8 * 128)()
+    assert lib.bvc_comm_init(3, 2, ident, ctypes.byref(h)) != 0 and b"rank 3 of 2" in lib.bvc_last_error()
+    assert lib.bvc_comm_rank(None) == -1 and lib.bvc_comm_world(None) == -1 and lib.bvc_comm_destroy(None) == 0
+    assert lib.bvc_allreduce_bucket(None, None, 0, 1, None) != 0 and lib.bvc_comm_wait(None, None) != 0
+    # with gloo / without a process group the Python shim never creates a communicator
+    assert bvc.comm.get() is None

@@ -57,6 +57,7 @@ def test_ddp_wrapper_rccl_single_rank():
                 g = model.flat_grads() / scaler.get_scale()
                 assert abs(float(loss) - ref_loss) / ref_loss < 1e-6
                 assert G.rel_err(g, ref_grad) < 1e-5
+                assert ddp.comm_backend == "bvc-rccl"      # the buckets went through bvc_allreduce_bucket, not torch.distributed
                 # several buckets were reduced on the comm stream and together they tile the whole buffer
                 covered = sorted(ddp.reduced_ranges)
                 assert len(covered) >= 2 and covered[0][0] == 0 and covered[-1][1] == ref_grad.numel()
@@ -72,6 +73,7 @@ def test_ddp_wrapper_rccl_single_rank():
         stats = bvc.grad_logger(ddp.module.named_parameters())
         assert stats.dec_last_layer > 0
     finally:
+        bvc.comm.reset()
         dist.destroy_process_group()
 
 
@@ -135,6 +137,7 @@ def test_ddp_jepa_three_wraps_rccl_single_rank():
         bvc.jepa.ema_update(enc, tgt, 0.99)
         torch.cuda.synchronize()
     finally:
+        bvc.comm.reset()
         dist.destroy_process_group()
 
 
@@ -178,4 +181,50 @@ def test_ddp_composite_simclr_vit_rccl_single_rank():
         cov = sorted(ddp.reduced_ranges)
         assert cov[0][0] == 0 and cov[-1][1] == model.trunk.flat_grads().numel()
     finally:
+        bvc.comm.reset()
+        dist.destroy_process_group()
+
+
+def test_library_communicator_single_rank():
+    """include/bvc.h "communication" through the Python shim: rendezvous over the process group, bucket all-reduce on the
+    library's stream with its fences, collectives on the caller's stream, and the torch.distributed A/B switch."""
+    _rccl_group(29537)
+    try:
+        c = bvc.comm.get(dev)
+        assert c is not None and (c.rank, c.world) == (0, 1)
+        assert "rccl" in c.library.lower()
+        x = torch.randn(1 << 20, device=dev)
+        want = x.clone()
+        y = x * 2.0                      # producer kernel on the current stream; the bucket must be ordered after it
+        c.allreduce_bucket(y, average=True)
+        c.wait()
+        z = y + 1.0                      # consumer on the current stream, ordered after the bucket by wait()
+        torch.cuda.synchronize()
+        assert torch.equal(z, want * 2.0 + 1.0)
+        g = torch.empty(1 * 6, device=dev)
+        c.allgather(torch.arange(6, device=dev, dtype=torch.float32), g)
+        b = torch.arange(10, device=dev, dtype=torch.float32)
+        c.broadcast(b, 0)
+        s = torch.full((8,), 3.0, device=dev)
+        c.allreduce(s, average=False)
+        torch.cuda.synchronize()
+        assert torch.equal(g, torch.arange(6, device=dev, dtype=torch.float32)) and torch.equal(b, torch.arange(10, device=dev, dtype=torch.float32))
+        assert torch.equal(s, torch.full((8,), 3.0, device=dev))
+        # the autograd node of the SimCLR global-batch loss takes the same route and stays the identity with one rank
+        e = torch.randn(8, 16, device=dev, requires_grad=True)
+        out = bvc.distributed.AllGather.apply(e)
+        out.sum().backward()
+        assert torch.equal(out, e) and torch.equal(e.grad, torch.ones_like(e))
+    finally:
+        bvc.comm.reset()
+        dist.destroy_process_group()
+
+
+def test_torch_distributed_fallback_switch(monkeypatch):
+    monkeypatch.setenv("BVC_COMM", "torch")
+    _rccl_group(29538)
+    try:
+        assert bvc.comm.get(dev) is None
+    finally:
+        bvc.comm.reset()
         dist.destroy_process_group()

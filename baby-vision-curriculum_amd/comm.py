@@ -112,11 +112,29 @@ def get(device=None):
         return None
     _tried = True
     device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    def agreed(flag):
+        t = torch.tensor([1.0 if flag else 0.0], device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return float(t) >= 1.0
+
+    # before anyone enters ncclCommInitRank (which waits for every rank): can each rank reach an RCCL library at all?
+    where = _lib.lib().bvc_comm_library().decode()
+    if not agreed("librccl" in where and "[" not in where):
+        warnings.warn(f"bvc communicator unavailable (RCCL: {where}); the step's collectives stay on torch.distributed")
+        return None
+    err = None
     try:
-        _comm = _create(device)
-    except Exception as e:   # every rank takes the same branch: the failure modes (library missing, init error) are per-machine
-        warnings.warn(f"bvc communicator unavailable ({e}); the step's collectives stay on torch.distributed")
-        _comm = None
+        made = _create(device)
+    except Exception as e:
+        made, err = None, e
+    # all ranks or none: a rank that failed alone would otherwise leave the others waiting in their first bucket
+    if not agreed(made is not None):
+        if made is not None:
+            made.close()
+        warnings.warn(f"bvc communicator unavailable on at least one rank ({err or 'another rank failed'}); "
+                      "the step's collectives stay on torch.distributed")
+        made = None
+    _comm = made
     return _comm
 
 

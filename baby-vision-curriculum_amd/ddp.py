@@ -82,6 +82,8 @@ class DistributedDataParallel(nn.Module):
         self._loose = [p for p in module.parameters() if id(p) not in owned] if isinstance(module, nn.Module) else []
         self._loose_grad = [p for p in self._loose if p.requires_grad]
         self._loose_seen = 0
+        if self._device is not None and self._device.type == "cuda":
+            self._native_comm(self._device)       # create the library communicator now (rendezvous + probe), not inside the first backward
         if broadcast_parameters:
             self._broadcast()
         for st in self._flats:

@@ -564,6 +564,7 @@ static int pick_gemm8(const GemmProblem* probs, int nprob, GemmLayout layout) {
     if (off || nprob != 1 || layout == GEMM_TN) return -1;
     const GemmProblem& p = probs[0];
     if (p.split_k != 1 || p.K % 64 != 0) return -1;
+    if (p.a_bytes >= 0x80000000u || p.b_bytes >= 0x80000000u) return -1;    // gemm8 addresses operands below 2 GiB (its out-of-range sentinel)
     const bool bf = p.epi == EPI_BF16 || p.epi == EPI_GELU || p.epi == EPI_RELU;
     const bool resid = (p.epi == EPI_RESID || p.epi == EPI_POS || p.epi == EPI_F32) && layout == GEMM_NT;    // f32 out (+ f32 side input)
     if (!bf && !resid) return -1;

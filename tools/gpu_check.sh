@@ -85,6 +85,11 @@ PY
            cd $R
            run traffic 60 python tools/pmc_traffic.py $OUT/pmct/rd $OUT/pmct/wr 3 ${BVC_BATCH:-256} $OUT/traffic_b${BVC_BATCH:-256}.json
            find $OUT/pmct -name "*.csv" -size +5M -delete ;;
+    mfma)  rm -rf $OUT/pmcm; cd /tmp
+           run mfma_pmc 400 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES --output-format csv -d $OUT/pmcm -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --batch ${BVC_BATCH:-256}
+           cd $R
+           run mfma_table 60 python tools/pmc_mfma_step.py $OUT/pmcm 3 $OUT/mfma_busy_b${BVC_BATCH:-256}.txt
+           find $OUT/pmcm -name "*.csv" -size +5M -delete ;;
     profdefault) rm -rf $OUT/profd; cd /tmp
            run profdefault 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/profd -- python3 $R/bench.py
            cd $R; find $OUT/profd -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/kernel_stats_default.csv

@@ -40,6 +40,8 @@ __device__ __forceinline__ float wave_max(float v) {
 // erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, far below the bf16 rounding of the result): one v_rcp, one
 // v_exp and five FMAs instead of libm erff's ~40 VALU - the GELU epilogues were doubling the fc1 / dX-fc2 GEMMs.
 // gelu and gelu' share the exponential: with z = x / sqrt(2),  exp(-z^2) = exp(-x^2 / 2).
+// The FORWARD epilogue computes both and saves gelu'(pre) in place of the pre-activation (round 2): the backward product's epilogue is
+// then one multiply per element instead of ~14 vector instructions + 2 transcendentals that nothing hid on the one-workgroup-per-CU kernel.
 // Two elements at a time: the polynomial, the squares and the final combinations are v_pk_fma_f32 / v_pk_mul_f32 (one issue for
 // two elements), only the reciprocal and the exponential stay scalar - 18 instructions per PAIR instead of ~16 per element.
 // The GELU epilogues of the decoder's K = 384 products cost as much as their whole K loop (profiles/r02_c_gemm8_store_cost.txt).
@@ -62,24 +64,26 @@ __device__ __forceinline__ GeluParts2 gelu_parts2(f32x2 x) {
     g.erf_abs = __builtin_elementwise_fma(-p, g.e, f32x2{1.0f, 1.0f});
     return g;
 }
-__device__ __forceinline__ f32x2 gelu2(f32x2 x) {
+// gelu(x) and gelu'(x) of two elements from one set of parts (the forward epilogue stores both: the backward product then
+// multiplies by the stored derivative instead of re-deriving it from the pre-activation with a reciprocal and an exponential per element)
+__device__ __forceinline__ void gelu_and_grad2(f32x2 x, f32x2& act, f32x2& grad) {
     const GeluParts2 g = gelu_parts2(x);
-    return __builtin_elementwise_fma(g.ax, g.erf_abs, x) * 0.5f;
-}
-__device__ __forceinline__ f32x2 dgelu2(f32x2 x) {
-    const GeluParts2 g = gelu_parts2(x);
+    act = __builtin_elementwise_fma(g.ax, g.erf_abs, x) * 0.5f;
     f32x2 s;
     s.x = copysignf(g.erf_abs.x, x.x); s.y = copysignf(g.erf_abs.y, x.y);
     const f32x2 phi = __builtin_elementwise_fma(s, f32x2{0.5f, 0.5f}, f32x2{0.5f, 0.5f});
-    return __builtin_elementwise_fma(x * 0.39894228040143268f, g.e, phi);
+    grad = __builtin_elementwise_fma(x * 0.39894228040143268f, g.e, phi);
 }
-// in place on an array of 2n floats
+// v[0 .. 2n) -> gelu'(v) in place, gelu(v) to act[]
 template <int N2>
-__device__ __forceinline__ void gelu_inplace(float (&v)[N2]) {
+__device__ __forceinline__ void gelu_split(float (&v)[N2], float (&act)[N2]) {
 #pragma unroll
-    for (int e = 0; e < N2; e += 2) { const f32x2 r = gelu2(f32x2{v[e], v[e + 1]}); v[e] = r.x; v[e + 1] = r.y; }
+    for (int e = 0; e < N2; e += 2) {
+        f32x2 a, d;
+        gelu_and_grad2(f32x2{v[e], v[e + 1]}, a, d);
+        act[e] = a.x; act[e + 1] = a.y; v[e] = d.x; v[e + 1] = d.y;
+    }
 }
-
 // buffer resource over [base, base+bytes): out-of-range lanes of a buffer load return 0
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, uint32_t bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);

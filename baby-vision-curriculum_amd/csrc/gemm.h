@@ -15,12 +15,12 @@ enum GemmLayout { GEMM_NT = BVC_GEMM_NT, GEMM_NN = BVC_GEMM_NN, GEMM_TN = BVC_GE
 enum GemmEpilogue {
     EPI_F32 = BVC_EPI_F32,          // C f32 = v (+bias)            ; split_k>1: atomicAdd into C (C pre-zeroed / accumulating)
     EPI_BF16 = BVC_EPI_BF16,        // C bf16 = v (+bias)
-    EPI_GELU = BVC_EPI_GELU,        // C bf16 = v+bias (pre-activation), C2 bf16 = gelu(v+bias)
+    EPI_GELU = BVC_EPI_GELU,        // C bf16 = gelu'(v+bias) (what the backward product multiplies by), C2 bf16 = gelu(v+bias)
     EPI_RESID = BVC_EPI_RESID,      // C f32 = resid + v + bias      (resid may alias C); split_k>1: atomicAdd, resid must alias C
     EPI_POS = BVC_EPI_POS,          // C f32 = v + bias + pos[rowtok[m]][n]
     EPI_E2D = BVC_EPI_E2D,          // C f32[(m/rin)*rout + m%rin][n] = v + pos[rowtok[m]][n]
     EPI_LOSS = BVC_EPI_LOSS,        // d = v + bias - labels[m][n]; C bf16 = d; C2 f32 = v+bias (optional); partial[tile] = sum d^2
-    EPI_DGELU = BVC_EPI_DGELU,      // C bf16 = v * gelu'(aux[m][n])
+    EPI_DGELU = BVC_EPI_DGELU,      // C bf16 = v * aux[m][n], aux = the gelu' saved by EPI_GELU
     EPI_F32_BF16 = BVC_EPI_F32_BF16, // C f32 = v (+bias), C2 bf16 = same value
     EPI_RELU = BVC_EPI_RELU,         // C bf16 = relu(v + bias)
     EPI_DRELU = BVC_EPI_DRELU,       // C bf16 = v * (aux > 0)

@@ -320,11 +320,9 @@ __global__ __launch_bounds__(256, LB) void gemm_kernel(const GemmGroup g) {
                 } break;
                 case EPI_BF16: store_bf16(p.C, idx, v); break;
                 case EPI_GELU: {
-                    store_bf16(p.C, idx, v);
                     float a[8];
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) a[e] = v[e];
-                    gelu_inplace(a);
+                    gelu_split(v, a);              // v <- gelu'(pre), a <- gelu(pre)
+                    store_bf16(p.C, idx, v);
                     store_bf16(p.C2, idx, a);
                 } break;
                 case EPI_RESID: {
@@ -358,10 +356,9 @@ __global__ __launch_bounds__(256, LB) void gemm_kernel(const GemmGroup g) {
                     const uint32_t w[4] = {__float_as_uint(side0[it][0]), __float_as_uint(side0[it][1]), __float_as_uint(side0[it][2]),
                                            __float_as_uint(side0[it][3])};
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const f32x2 dg = dgelu2(f32x2{__uint_as_float(w[e] << 16), __uint_as_float(w[e] & 0xffff0000u)});
-                        v[2 * e] *= dg.x;
-                        v[2 * e + 1] *= dg.y;
+                    for (int e = 0; e < 4; ++e) {      // aux = gelu'(pre), saved by the forward epilogue
+                        v[2 * e] *= __uint_as_float(w[e] << 16);
+                        v[2 * e + 1] *= __uint_as_float(w[e] & 0xffff0000u);
                     }
                     store_bf16(p.C, idx, v);
                 } break;
@@ -565,15 +562,19 @@ static int pick_gemm8(const GemmProblem* probs, int nprob, GemmLayout layout) {
     const GemmProblem& p = probs[0];
     if (p.split_k != 1 || p.K % 64 != 0) return -1;
     if (p.a_bytes >= 0x80000000u || p.b_bytes >= 0x80000000u) return -1;    // gemm8 addresses operands below 2 GiB (its out-of-range sentinel)
+    // (the gated epilogues - GELU' / ReLU' - joined once the forward saved gelu' itself: one multiply per element instead of ~14
+    //  vector instructions nothing hid on this kernel; decoder dX-fc2 at 256 clips 769 vs 878 us - profiles/r02_i_gelu_grad_saved.txt)
+    const bool gated = p.epi == EPI_DGELU || p.epi == EPI_DRELU;
     const bool bf = p.epi == EPI_BF16 || p.epi == EPI_GELU || p.epi == EPI_RELU;
     const bool resid = (p.epi == EPI_RESID || p.epi == EPI_POS || p.epi == EPI_F32) && layout == GEMM_NT;    // f32 out (+ f32 side input)
-    if (!bf && !resid) return -1;
+    if (!bf && !resid && !gated) return -1;
     if (2.0 * p.M * p.N * p.K < 45e9) return -1;
     const int tm = (p.M + 255) / 256, tn256 = (p.N + 255) / 256, tn128 = (p.N + 127) / 128;
     const bool full256 = (double)p.N >= 0.85 * 256.0 * tn256;
     // (the f32 class runs its side inputs in four passes on 256 x 256 tiles: encoder proj / fc2 / patch embedding at 256 clips
     //  -10 / -21 / -17 %, a loss below 448 tiles - profiles/r02_g_gemm8_resid_ab.txt)
     if (full256 && tm * tn256 >= 448) return 10;
+    if (gated) return -1;                   // 256 x 128 tiles lose on them at every size measured
     if ((bf ? layout == GEMM_NN : p.N <= 384) && p.K >= 1024 && tm * tn128 >= (resid ? 1024 : 224)) return 11;
     return -1;
 }

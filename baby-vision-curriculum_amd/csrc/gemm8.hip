@@ -465,14 +465,16 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const GemmGroup g, const 
                         // even lane rows: own tile-2jp columns, then lane + 16's; odd lane rows: lane - 16's tile-(2jp+1) columns, then own
                         __builtin_amdgcn_raw_buffer_store_b128(u32x4{s0[0], s1[0], s0[1], s1[1]}, r, o, 0, 0);
                     };
-                    emit(rc);
-                    if (two_out) {
+                    if (two_out) {      // EPI_GELU: C <- gelu'(pre), C2 <- gelu(pre)
+                        float ga[4], gb[4];
+                        gelu_split(va, ga);
+                        gelu_split(vb, gb);
+                        emit(rc);
 #pragma unroll
-                        for (int e = 0; e < 4; e += 2) {
-                            const f32x2 ga = gelu2(f32x2{va[e], va[e + 1]}), gb = gelu2(f32x2{vb[e], vb[e + 1]});
-                            va[e] = ga.x; va[e + 1] = ga.y; vb[e] = gb.x; vb[e + 1] = gb.y;
-                        }
+                        for (int e = 0; e < 4; ++e) { va[e] = ga[e]; vb[e] = gb[e]; }
                         emit(rc2);
+                    } else {
+                        emit(rc);
                     }
                 }
             }
@@ -589,10 +591,9 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const GemmGroup g, const 
                         if (epi == EPI_DGELU) {
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
-                                const uint32_t w = __float_as_uint(side0[c][e]);
-                                const f32x2 dg = dgelu2(f32x2{__uint_as_float(w << 16), __uint_as_float(w & 0xffff0000u)});
-                                v[2 * e] *= dg.x;
-                                v[2 * e + 1] *= dg.y;
+                                const uint32_t w = __float_as_uint(side0[c][e]);      // aux = gelu'(pre), saved by the forward epilogue
+                                v[2 * e] *= __uint_as_float(w << 16);
+                                v[2 * e + 1] *= __uint_as_float(w & 0xffff0000u);
                             }
                         } else {     // EPI_DRELU: aux = the forward ReLU output, the gradient passes where it was positive
 #pragma unroll

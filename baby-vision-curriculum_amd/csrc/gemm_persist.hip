@@ -253,11 +253,9 @@ __global__ __launch_bounds__(256, 2) void gemm_persist_kernel(const GemmGroup g)
                     case EPI_F32: store_f32(reinterpret_cast<float*>(p.C) + idx); break;
                     case EPI_BF16: store_bf16(p.C, v, false); break;
                     case EPI_GELU: {
-                        store_bf16(p.C, v, false);
                         float a[8];
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) a[e] = v[e];
-                        gelu_inplace(a);
+                        gelu_split(v, a);          // v <- gelu'(pre), a <- gelu(pre)
+                        store_bf16(p.C, v, false);
                         store_bf16(p.C2, a, true);
                     } break;
                     case EPI_RESID: {
@@ -270,10 +268,9 @@ __global__ __launch_bounds__(256, 2) void gemm_persist_kernel(const GemmGroup g)
                     case EPI_DGELU: {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            const uint32_t w = __float_as_uint(side0[c][e]);
-                            const f32x2 dg = dgelu2(f32x2{__uint_as_float(w << 16), __uint_as_float(w & 0xffff0000u)});
-                            v[2 * e] *= dg.x;
-                            v[2 * e + 1] *= dg.y;
+                            const uint32_t w = __float_as_uint(side0[c][e]);      // aux = gelu'(pre), saved by the forward epilogue
+                            v[2 * e] *= __uint_as_float(w << 16);
+                            v[2 * e + 1] *= __uint_as_float(w & 0xffff0000u);
                         }
                         store_bf16(p.C, v, false);
                     } break;

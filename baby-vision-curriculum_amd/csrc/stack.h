@@ -44,7 +44,7 @@ struct LayerAct {
     bf16_t* ctx;      // bf16 [M][D]
     float* lse;       // f32 [B*H][N]
     bf16_t* ln2o;     // bf16 [M][D]
-    bf16_t* pre;      // bf16 [M][I]
+    bf16_t* pre;      // bf16 [M][I]: gelu'(fc1 pre-activation), written by the forward fc1 epilogue for the backward dX-fc2 product
     bf16_t* act;      // bf16 [M][I]
     float *mean1, *rstd1, *mean2, *rstd2;
 };

@@ -203,6 +203,9 @@ enum {
     BVC_EPI_LOSS = 6, BVC_EPI_DGELU = 7, BVC_EPI_F32_BF16 = 8, BVC_EPI_RELU = 9, BVC_EPI_DRELU = 10,
     BVC_EPI_NCE = 11, BVC_EPI_NCE_BWD = 12
 };
+/* BVC_EPI_GELU writes TWO bf16 outputs: C2 = gelu(v + bias) and C = gelu'(v + bias), the factor the backward product needs (the
+ * forward epilogue has the erf and the exponential at hand; the backward epilogue BVC_EPI_DGELU, C = v * aux with aux = that C, is
+ * then one multiply per element).  BVC_EPI_RELU / BVC_EPI_DRELU: C = max(v + bias, 0) / C = v where aux > 0. */
 /* C[M,N] = epilogue(alpha * alpha_dev[0] * sum_k A(m,k) B(k,n)); bf16 operands, f32 accumulation.
  * Replaces the nn.Linear forward / backward GEMMs that ATen dispatches for HF:225-237,269-275,299-322. */
 typedef struct bvc_gemm_desc {

@@ -294,17 +294,18 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
 template <int HD, int KOFF, int VOFF>
 __device__ __forceinline__ void dq_subtile(const AS3 char* lds, const FragAddr<HD>& fa, const bf16x8 (&qf)[HD / 16],
                                            const bf16x8 (&dof)[HD / 16], f32x16 (&dq)[HD / 32], int key0, int N, int h,
-                                           float scale_log2, float nlse, float del_q) {
+                                           float scale_log2, float nlse, const f32x16& ndel) {
     constexpr int KS = 16 * HD * 2;
-    f32x16 s = zero16(), dp = zero16();
+    // the dP^T chain starts from -delta (a loop-invariant register tuple: this lane's query is fixed), so dP - delta costs nothing here
+    f32x16 s = zero16(), dp;
 #pragma unroll
     for (int stp = 0; stp < HD / 16; ++stp) {
         s = MFMA32(lds_rows<KOFF>(lds, fa.rows[stp]), qf[stp], s);
-        dp = MFMA32(lds_rows<VOFF>(lds, fa.rows[stp]), dof[stp], dp);
+        dp = MFMA32(lds_rows<VOFF>(lds, fa.rows[stp]), dof[stp], stp == 0 ? ndel : dp);
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r)   // dS^T (without the 1/sqrt(d) factor, applied at the end)
-        s[r] = fast_exp2(fmaf(s[r], scale_log2, nlse)) * (dp[r] - del_q);
+        s[r] = fast_exp2(fmaf(s[r], scale_log2, nlse)) * dp[r];
     if (key0 + 32 > N) {
         asm volatile("" ::: "memory");
 #pragma unroll
@@ -357,11 +358,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
         }
     }
     del_q += __shfl_xor(del_q, 32, 64);
-    if (h == 0 && qi < N) delta[(size_t)bh * N + qi] = del_q;      // the dK/dV kernel, launched after this one, reads it
+    if (h == 0 && qi < N) delta[(size_t)bh * N + qi] = -del_q;     // NEGATED: the dK/dV kernel, launched after this one, starts its dP chain from it
     float nlse = -lse[(size_t)bh * N + qc];
 #pragma unroll
     for (int stq = 0; stq < HD / 16; ++stq) { settle(qf[stq]); settle(dof[stq]); }
     settle(nlse); settle(del_q);
+    f32x16 ndel;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ndel[r] = -del_q;
     f32x16 dq[HD / 32];
 #pragma unroll
     for (int t = 0; t < HD / 32; ++t) dq[t] = zero16();
@@ -377,15 +381,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (kt + 1 < nkt) issue(kt + 1, 1);
-        dq_subtile<HD, 0, IMG>(lds, fa, qf, dof, dq, kt * 64, N, h, scale_log2, nlse, del_q);
-        if (kt * 64 + 32 < N) dq_subtile<HD, SUB, IMG + SUB>(lds, fa, qf, dof, dq, kt * 64 + 32, N, h, scale_log2, nlse, del_q);
+        dq_subtile<HD, 0, IMG>(lds, fa, qf, dof, dq, kt * 64, N, h, scale_log2, nlse, ndel);
+        if (kt * 64 + 32 < N) dq_subtile<HD, SUB, IMG + SUB>(lds, fa, qf, dof, dq, kt * 64 + 32, N, h, scale_log2, nlse, ndel);
         if (kt + 1 >= nkt) break;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (kt + 2 < nkt) issue(kt + 2, 0);
-        dq_subtile<HD, STG, STG + IMG>(lds, fa, qf, dof, dq, kt * 64 + 64, N, h, scale_log2, nlse, del_q);
+        dq_subtile<HD, STG, STG + IMG>(lds, fa, qf, dof, dq, kt * 64 + 64, N, h, scale_log2, nlse, ndel);
         if (kt * 64 + 96 < N)
-            dq_subtile<HD, STG + SUB, STG + IMG + SUB>(lds, fa, qf, dof, dq, kt * 64 + 96, N, h, scale_log2, nlse, del_q);
+            dq_subtile<HD, STG + SUB, STG + IMG + SUB>(lds, fa, qf, dof, dq, kt * 64 + 96, N, h, scale_log2, nlse, ndel);
     }
     if (qi < N) {
         bf16_t* orow = dqkv + (size_t)(b * N + qi) * ld + head * HD;
@@ -632,7 +636,7 @@ __global__ __launch_bounds__(64) void attn_bwd_dq_w_kernel(const bf16_t* __restr
             for (int j = 0; j < 8; ++j) dl += bf2f((bf16_t)dof[blk][stp][j]) * bf2f((bf16_t)of[j]);
         }
         dl += __shfl_xor(dl, 32, 64);
-        if (h == 0 && qi < N) delta[(size_t)bh * N + qi] = dl;      // the dK/dV kernel, launched after this one, reads it
+        if (h == 0 && qi < N) delta[(size_t)bh * N + qi] = -dl;     // negated, as attn_bwd_dq_kernel stores it
         del_q[blk] = dl;
         nlse[blk] = -lse[(size_t)bh * N + qc];
     }
@@ -722,31 +726,37 @@ __global__ __launch_bounds__(64) void attn_bwd_dq_w_kernel(const bf16_t* __restr
 #endif  // BVC_EXPERIMENTS
 
 // ============================================================================ dK, dV
-// LDS stage = Q image | dO image | -lse 256 B | delta 256 B
+// LDS stage = Q image | dO image | lse 256 B | -delta 256 B
 template <int HD, int QOFF, int STAT>
 __device__ __forceinline__ void dkdv_subtile(const AS3 char* lds, const FragAddr<HD>& fa, const bf16x8 (&kf)[HD / 16],
                                              const bf16x8 (&vf)[HD / 16], f32x16 (&dk)[HD / 32], f32x16 (&dv)[HD / 32], int q0,
                                              int N, int h, float scale_log2) {
     constexpr int IMG = 64 * HD * 2, KS = 16 * HD * 2;
     constexpr int DOFF = QOFF + IMG;
-    f32x16 s = zero16(), dp = zero16();
+    // rows of s/dp are queries: registers 4g..4g+3 <-> queries q0 + 8 g + 4 h + 0..3 (lse / -delta broadcast from LDS).
+    // The dP chain starts from -delta (the dQ kernel stores it negated): four 16-byte LDS reads ARE the initial accumulator.
+    const AS3 float* stl = reinterpret_cast<const AS3 float*>(lds + STAT) + 4 * h;
+    f32x16 s = zero16(), dp;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const f32x4 nd = *reinterpret_cast<const AS3 f32x4*>(stl + 64 + 8 * g);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dp[4 * g + e] = nd[e];
+    }
 #pragma unroll
     for (int stp = 0; stp < HD / 16; ++stp) {
         s = MFMA32(lds_rows<QOFF>(lds, fa.rows[stp]), kf[stp], s);
         dp = MFMA32(lds_rows<DOFF>(lds, fa.rows[stp]), vf[stp], dp);
     }
-    // rows of s/dp are queries: registers 4g..4g+3 <-> queries q0 + 8 g + 4 h + 0..3 (lse / delta broadcast from LDS)
-    const AS3 float* stl = reinterpret_cast<const AS3 float*>(lds + STAT) + 4 * h;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         const f32x4 ls = *reinterpret_cast<const AS3 f32x4*>(stl + 8 * g);
-        const f32x4 de = *reinterpret_cast<const AS3 f32x4*>(stl + 64 + 8 * g);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int r = 4 * g + e;
             const float p = fast_exp2(fmaf(s[r], scale_log2, -ls[e]));
             s[r] = p;
-            dp[r] = p * (dp[r] - de[e]);
+            dp[r] = p * dp[r];
         }
     }
     if (q0 + 32 > N) {

@@ -104,6 +104,9 @@ def _create(device):
 def get(device=None):
     """This process's communicator on `device`, created on first use; None when torch.distributed is not running on RCCL."""
     global _comm, _tried
+    if _comm is not None and (not (dist.is_available() and dist.is_initialized()) or
+                              (dist.get_rank(), dist.get_world_size()) != (_comm.rank, _comm.world)):
+        reset()          # the process group it was created for is gone (destroy_process_group / a new init): never reuse it
     if _comm is not None or _tried:
         return _comm
     if not (dist.is_available() and dist.is_initialized()) or dist.get_backend() != "nccl" or not torch.cuda.is_available():

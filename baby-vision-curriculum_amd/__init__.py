@@ -17,6 +17,6 @@ from .ddp import DistributedDataParallel  # noqa: F401
 from .ddputils import AllReduce  # noqa: F401
 from .loggingtools import grad_logger  # noqa: F401
 from . import optim, amp  # noqa: F401
-from . import simclr, distributed, jepa, jepa_mask, checkpoint, launch, comm  # noqa: F401
+from . import simclr, distributed, jepa, jepa_mask, checkpoint, launch, comm, probe  # noqa: F401
 from . import input as input_pipeline  # noqa: F401
 from .input import ClipUploadRing  # noqa: F401

@@ -77,6 +77,8 @@ BUCKET_FN = ctypes.CFUNCTYPE(None, c_int64, c_int64, c_void_p)
 SYMBOLS = {
     "bvc_last_error": (c_char_p, []),
     "bvc_version": (c_char_p, []),
+    "bvc_set_option": (c_int, [c_char_p, c_int]),
+    "bvc_get_option": (c_int, [c_char_p]),
     "bvc_videomae_param_count": (c_int, [ctypes.POINTER(VideoMAEConfigC)]),
     "bvc_videomae_param_numel": (c_int64, [ctypes.POINTER(VideoMAEConfigC)]),
     "bvc_videomae_param_info": (c_int, [ctypes.POINTER(VideoMAEConfigC), c_int, ctypes.c_char_p, c_int,
@@ -122,8 +124,11 @@ SYMBOLS = {
     "bvc_op_token_mean_bwd": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "bvc_op_gemm": (c_int, [ctypes.POINTER(GemmDesc), c_int, c_int, c_int, c_int, c_void_p]),
     "bvc_op_gemm_num_tiles": (c_int, [ctypes.POINTER(GemmDesc), c_int]),
+    "bvc_op_gemm_kernel": (c_int, [ctypes.POINTER(GemmDesc), c_int, c_int, c_int, c_int, ctypes.c_char_p, c_int]),
+    "bvc_op_gemm_plan_dw": (c_int, [ctypes.POINTER(GemmDesc), c_int]),
     "bvc_op_attention_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "bvc_op_attention_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "bvc_op_attention_bwd_part": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "bvc_op_layernorm_fwd": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_int, c_int, c_float, c_void_p]),
     "bvc_op_layernorm_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
@@ -180,6 +185,13 @@ def check(rc, what=""):
     if rc != 0:
         msg = lib().bvc_last_error()
         raise BvcError(f"{what} failed with status {rc}: {msg.decode() if msg else ''}")
+
+
+def set_option(name, value):
+    """bvc_set_option (include/bvc.h): "gemm8" -1 / 0 / 1, "dw_overlap" 0 / 1.  Returns the previous value."""
+    old = lib().bvc_get_option(name.encode())
+    check(lib().bvc_set_option(name.encode(), int(value)), "bvc_set_option")
+    return old
 
 
 def current_stream_ptr():

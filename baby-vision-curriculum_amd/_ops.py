@@ -14,7 +14,7 @@ def _p(t):
 
 
 def gemm_desc(A, B, M, N, K, epi, C, ldc=None, lda=None, ldb=None, alpha=1.0, alpha_dev=None, split_k=1, C2=None, bias=None,
-              resid=None, aux=None, labels=None, partial=None, rowsum=None):
+              resid=None, aux=None, labels=None, partial=None, rowsum=None, rowtok=None, pos=None, rin=0, rout=0):
     d = _lib.GemmDesc()
     d.A, d.B = A.data_ptr(), B.data_ptr()
     d.M, d.N, d.K = M, N, K
@@ -28,12 +28,33 @@ def gemm_desc(A, B, M, N, K, epi, C, ldc=None, lda=None, ldb=None, alpha=1.0, al
     d.C2, d.bias, d.resid, d.aux = _p(C2), _p(bias), _p(resid), _p(aux)
     d.ldaux = aux.shape[-1] if aux is not None else 0
     d.labels, d.partial, d.rowsum = _p(labels), _p(partial), _p(rowsum)
+    d.rowtok, d.pos, d.rin, d.rout = _p(rowtok), _p(pos), rin, rout
     return d
 
 
 def gemm(desc, layout, tile=-1, stages=-1):
-    arr = (_lib.GemmDesc * 1)(desc)
-    _lib.check(_lib.lib().bvc_op_gemm(arr, 1, layout, tile, stages, _lib.current_stream_ptr()), "bvc_op_gemm")
+    """One problem (a GemmDesc) or a group of up to four (a list) as ONE launch."""
+    descs = list(desc) if isinstance(desc, (list, tuple)) else [desc]
+    arr = (_lib.GemmDesc * len(descs))(*descs)
+    _lib.check(_lib.lib().bvc_op_gemm(arr, len(descs), layout, tile, stages, _lib.current_stream_ptr()), "bvc_op_gemm")
+
+
+def gemm_kernel_name(desc, layout, tile=-1, stages=-1):
+    """The kernel instantiation `gemm` would launch for these problems, as rocprofv3 names it (bvc_op_gemm_kernel; launches nothing)."""
+    descs = list(desc) if isinstance(desc, (list, tuple)) else [desc]
+    arr = (_lib.GemmDesc * len(descs))(*descs)
+    buf = ctypes.create_string_buffer(160)
+    _lib.check(_lib.lib().bvc_op_gemm_kernel(arr, len(descs), layout, tile, stages, buf, 160), "bvc_op_gemm_kernel")
+    return buf.value.decode()
+
+
+def plan_dw(descs):
+    """(tile config, split_k) the step uses for a group of weight-gradient products; split_k is written into the descriptors."""
+    arr = (_lib.GemmDesc * len(descs))(*descs)
+    tile = _lib.lib().bvc_op_gemm_plan_dw(arr, len(descs))
+    for d, a in zip(descs, arr):
+        d.split_k = a.split_k
+    return tile, arr[0].split_k
 
 
 def num_tiles(desc, tile=-1):

@@ -881,13 +881,14 @@ static int fwd_hd(const bf16_t* qkv, bf16_t* ctx, float* lse, int B, int N, int 
 
 template <int HD>
 static int bwd_hd(const bf16_t* qkv, const bf16_t* ctx, const bf16_t* dctx, const float* lse, float* delta, bf16_t* dqkv, int B,
-                  int N, int H, hipStream_t stream, float sm_scale) {
+                  int N, int H, hipStream_t stream, float sm_scale, int parts) {
     const int D = H * HD;
     const size_t bytes = (size_t)B * N * 3 * D * 2;
     const float scale = sm_scale > 0.f ? sm_scale : 1.0f / sqrtf((float)HD), scale_log2 = scale * 1.4426950408889634f;
     const dim3 grid((unsigned)(((N + 127) / 128) * B * H));
     const int remap = xcd_remap();
     // dQ first: it also produces delta = rowsum(dO * O), which the dK/dV kernel consumes
+    if (parts & 1) {
 #ifdef BVC_EXPERIMENTS
     if (getenv("BVC_ATTN_DQ_W") != nullptr) {      // the single-wave 96-query dQ kernel (see above): same-process A/B only
         constexpr int NB = 3;
@@ -898,6 +899,8 @@ static int bwd_hd(const bf16_t* qkv, const bf16_t* ctx, const bf16_t* dctx, cons
 #endif
     hipLaunchKernelGGL(attn_bwd_dq_kernel<HD>, grid, dim3(256), 4 * 64 * HD * 2, stream, qkv, dctx, ctx, lse, delta, dqkv, N, H, D,
                        (uint32_t)bytes, scale, scale_log2, remap);
+    }
+    if (parts & 2)
     hipLaunchKernelGGL(attn_bwd_dkdv_kernel<HD>, grid, dim3(256), 2 * (2 * 64 * HD * 2 + 512), stream, qkv, dctx, lse, delta, dqkv, N, H, D,
                        (uint32_t)bytes, (uint32_t)((size_t)B * N * D * 2), (uint32_t)((size_t)B * H * N * 4), scale, scale_log2, remap);
     BVC_CHECK_HIP(hipGetLastError());
@@ -912,12 +915,12 @@ int launch_attn_fwd(const bf16_t* qkv, bf16_t* ctx, float* lse, int B, int N, in
 }
 
 int launch_attn_bwd(const bf16_t* qkv, const bf16_t* ctx, const bf16_t* dctx, const float* lse, float* delta,
-                    bf16_t* dqkv, int B, int N, int H, int head_dim, hipStream_t stream, float sm_scale) {
+                    bf16_t* dqkv, int B, int N, int H, int head_dim, hipStream_t stream, float sm_scale, int parts) {
     BVC_REQUIRE(B > 0 && N > 0 && H > 0, "attn_bwd: empty shape");
     BVC_REQUIRE(head_dim == 64 || head_dim == 32, "attn_bwd: head_dim %d unsupported (32 or 64)", head_dim);
     BVC_REQUIRE((size_t)B * N * 3 * H * head_dim * 2 < 0xffffffffull, "attn_bwd: qkv larger than 4 GiB");
-    return head_dim == 64 ? bwd_hd<64>(qkv, ctx, dctx, lse, delta, dqkv, B, N, H, stream, sm_scale)
-                          : bwd_hd<32>(qkv, ctx, dctx, lse, delta, dqkv, B, N, H, stream, sm_scale);
+    return head_dim == 64 ? bwd_hd<64>(qkv, ctx, dctx, lse, delta, dqkv, B, N, H, stream, sm_scale, parts)
+                          : bwd_hd<32>(qkv, ctx, dctx, lse, delta, dqkv, B, N, H, stream, sm_scale, parts);
 }
 
 }  // namespace bvc

@@ -33,6 +33,18 @@ using GemmProblem = bvc_gemm_desc;
 
 constexpr int kMaxGroup = 4;
 
+// Process-wide switches behind bvc_set_option (include/bvc.h): what the parity tests and the same-process A/B tools flip.
+//   gemm8:      0 = the measured selection (pick_gemm8 / plan_dw), 1 = the 256-row persistent kernel for EVERY product it can take
+//               (whatever its size: how the tests run the bench's kernel set at oracle-sized batches), -1 = never
+//   dw_overlap: 1 = the grouped weight-gradient launch of a layer runs on the context's side stream (no gain measured; A/B only)
+struct Options { int gemm8 = 0; int dw_overlap = 0; };
+Options& options();
+
+// bvc_op_gemm_kernel: while `on`, the launchers write the name of the kernel instantiation they would launch (as rocprofv3
+// prints it) and launch nothing - what bench.py uses to attribute its per-product timings to the rows of a kernel-stats table.
+struct DryRun { bool on = false; char name[160] = ""; };
+DryRun& dry_run();
+
 // Launch 1..4 independent problems of the same layout as ONE grid (grouped GEMM) on `stream`.
 // tile_cfg: -1 = pick from the tile count; 0 = 128x128, 1 = 128x64, 2 = 64x64.
 // stages: -1 = pick from the grid size; 2..4 = LDS ring depth (K-steps of LDS-DMA in flight + 1).

@@ -22,13 +22,21 @@
 //     tiles, walked in column panels sized for its L2 (NT / NN) or along the short side with K-splits fastest (TN).
 //   * up to 4 independent problems per launch (grouped GEMM) to fill 256 CUs with the small
 //     weight-gradient products of one transformer layer; split-K with f32 atomics; fused bias gradients.
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "gemm_tile.h"
 
 namespace bvc {
 
-
+Options& options() {
+    static Options o;
+    return o;
+}
+DryRun& dry_run() {
+    static thread_local DryRun d;
+    return d;
+}
 
 // ------------------------------------------------------------------ the kernel
 // Two LDS slots; waits use a COUNTED vmcnt and raw s_barrier so that the refill DMA keeps flying across barriers
@@ -499,6 +507,11 @@ int gemm_num_tiles(const GemmProblem& p, int tile_cfg) { return tiles_for(p, gem
 template <int BM, int BN, bool AT, bool BT, int NS, int LB = 2, bool EARLY = true>
 static int launch_one(const GemmGroup& g, int nblocks, hipStream_t stream) {
     constexpr size_t lds = (size_t)NS * (BM + BN) * 64 * 2;
+    if (dry_run().on) {
+        snprintf(dry_run().name, sizeof(dry_run().name), "bvc::gemm_kernel<%d, %d, %s, %s, %d, %d, %s>", BM, BN, AT ? "true" : "false",
+                 BT ? "true" : "false", NS, LB, EARLY ? "true" : "false");
+        return BVC_OK;
+    }
     static bool attr_set = false;   // > 64 KiB of dynamic LDS needs the attribute once per kernel
     if (lds > 65536 && !attr_set) {
         BVC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<BM, BN, AT, BT, NS, LB, EARLY>),
@@ -557,8 +570,8 @@ int launch_gemm8(const GemmGroup& g, GemmLayout layout, int bn, hipStream_t stre
 //     launches below 45 GFLOP (at 16 clips gemm8 loses 5-50 % on every product).
 // Returns 10 / 11 (tile configs) or -1.
 static int pick_gemm8(const GemmProblem* probs, int nprob, GemmLayout layout) {
-    static const bool off = getenv("BVC_GEMM_NO_G8") != nullptr;
-    if (off || nprob != 1 || layout == GEMM_TN) return -1;
+    const int mode = options().gemm8;
+    if (mode < 0 || nprob != 1 || layout == GEMM_TN) return -1;
     const GemmProblem& p = probs[0];
     if (p.split_k != 1 || p.K % 64 != 0) return -1;
     if (p.a_bytes >= 0x80000000u || p.b_bytes >= 0x80000000u) return -1;    // gemm8 addresses operands below 2 GiB (its out-of-range sentinel)
@@ -568,22 +581,30 @@ static int pick_gemm8(const GemmProblem* probs, int nprob, GemmLayout layout) {
     const bool bf = p.epi == EPI_BF16 || p.epi == EPI_GELU || p.epi == EPI_RELU;
     const bool resid = (p.epi == EPI_RESID || p.epi == EPI_POS || p.epi == EPI_F32) && layout == GEMM_NT;    // f32 out (+ f32 side input)
     if (!bf && !resid && !gated) return -1;
-    if (2.0 * p.M * p.N * p.K < 45e9) return -1;
     const int tm = (p.M + 255) / 256, tn256 = (p.N + 255) / 256, tn128 = (p.N + 127) / 128;
+    // the register-epilogue class keeps the tile-padded bias vector in 32 KiB of LDS (launch_gemm8 refuses wider outputs)
+    const bool fits256 = !bf || (size_t)tn256 * 256 * 4 <= 32768, fits128 = !bf || (size_t)tn128 * 128 * 4 <= 32768;
+    if (mode > 0) {      // forced (tests, A/B tools): the widest tile the output fills at least half of
+        if (fits256 && (gated || p.N > 128)) return 10;
+        return fits128 && !gated ? 11 : -1;
+    }
+    if (2.0 * p.M * p.N * p.K < 45e9) return -1;
     const bool full256 = (double)p.N >= 0.85 * 256.0 * tn256;
     // (the f32 class runs its side inputs in four passes on 256 x 256 tiles: encoder proj / fc2 / patch embedding at 256 clips
     //  -10 / -21 / -17 %, a loss below 448 tiles - profiles/r02_g_gemm8_resid_ab.txt)
-    if (full256 && tm * tn256 >= 448) return 10;
+    if (full256 && fits256 && tm * tn256 >= 448) return 10;
     if (gated) return -1;                   // 256 x 128 tiles lose on them at every size measured
-    if ((bf ? layout == GEMM_NN : p.N <= 384) && p.K >= 1024 && tm * tn128 >= (resid ? 1024 : 224)) return 11;
+    if (fits128 && (bf ? layout == GEMM_NN : p.N <= 384) && p.K >= 1024 && tm * tn128 >= (resid ? 1024 : 224)) return 11;
     return -1;
 }
 
 int launch_gemm(const GemmProblem* probs, int nprob, GemmLayout layout, int tile_cfg, hipStream_t stream, int stages) {
     BVC_REQUIRE(nprob >= 1 && nprob <= kMaxGroup, "launch_gemm: nprob %d out of range", nprob);
-    if (tile_cfg < 0 && stages < 0) {
+    static thread_local bool skip_g8 = false;      // set while an auto-picked gemm8 launch that turned the problem down is re-planned
+    bool auto_g8 = false;
+    if (tile_cfg < 0 && stages < 0 && !skip_g8) {
         const int g8 = pick_gemm8(probs, nprob, layout);
-        if (g8 > 0) tile_cfg = g8;
+        if (g8 > 0) { tile_cfg = g8; auto_g8 = true; }
     }
     if ((tile_cfg >= 3 && tile_cfg <= 5) || tile_cfg == 8) {
 #ifdef BVC_EXPERIMENTS
@@ -631,6 +652,12 @@ int launch_gemm(const GemmProblem* probs, int nprob, GemmLayout layout, int tile
     for (int i = nprob; i < kMaxGroup; ++i) { g.prob[i] = probs[0]; g.panel[i] = g.panel[0]; g.tile_start[i + 1] = total; }
     if (cfg == 10 || cfg == 11) {
         const int rc = launch_gemm8(g, layout, cfg == 10 ? 256 : 128, stream);
+        if (rc == 1 && auto_g8) {     // the selection and the kernel's own eligibility test disagree: never an error for the caller
+            skip_g8 = true;
+            const int rc2 = launch_gemm(probs, nprob, layout, -1, stream, stages);
+            skip_g8 = false;
+            return rc2;
+        }
         BVC_REQUIRE(rc != 1, "launch_gemm: tile configs 10 / 11 (256-row persistent kernel) do not take this problem");
         return rc;
     }

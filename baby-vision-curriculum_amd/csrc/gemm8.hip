@@ -23,6 +23,7 @@
 // group (q + 2) & 3; the stream of groups never skips: past the last unit the loads are issued with an out-of-range offset
 // (the buffer descriptor drops them, the counter still counts them), which keeps every counted wait exact.
 // Results are bit-identical to gemm_kernel's for the same problem (same K order per output element, same epilogue math).
+#include <stdio.h>
 #include <stdlib.h>
 
 #include <type_traits>
@@ -675,6 +676,10 @@ template <int BN, bool AT, bool BT, int EC>
 static int launch_gemm8_one(const GemmGroup& g, int total, hipStream_t stream) {
     // two K-tile slots + the epilogue region: 16 parked rows per wave (classes 1-3) or the bias copy of class 0 (32 KiB: N <= 8192)
     constexpr size_t lds = 2 * (size_t)(256 + BN) * 64 * 2 + (EC == 0 ? (size_t)32768 : (size_t)8 * 16 * (BN / 4) * 4);
+    if (dry_run().on) {
+        snprintf(dry_run().name, sizeof(dry_run().name), "bvc::gemm8_kernel<%d, %s, %s, %d>", BN, AT ? "true" : "false", BT ? "true" : "false", EC);
+        return BVC_OK;
+    }
     static bool attr_set = false;
     if (!attr_set) {
         BVC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm8_kernel<BN, AT, BT, EC>),

@@ -18,6 +18,8 @@
 // bit-identical to gemm_kernel's.
 #include <stdlib.h>
 
+#include <stdio.h>
+
 #include "gemm_tile.h"
 
 namespace bvc {
@@ -297,6 +299,10 @@ __global__ __launch_bounds__(256, 2) void gemm_persist_kernel(const GemmGroup g)
 template <int BN, bool BT, int DEFER = 0>
 static int launch_persist_one(const GemmGroup& g, hipStream_t stream) {
     constexpr size_t lds = 2 * (size_t)(128 + BN) * 64 * 2 + 4 * 16 * (BN / 2) * 4;     // stages + parking: 80 KiB / 56 KiB
+    if (dry_run().on) {
+        snprintf(dry_run().name, sizeof(dry_run().name), "bvc::gemm_persist_kernel<%d, %s, %d>", BN, BT ? "true" : "false", DEFER);
+        return BVC_OK;
+    }
     static bool attr_set = false;
     if (lds > 65536 && !attr_set) {
         BVC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_persist_kernel<BN, BT, DEFER>),

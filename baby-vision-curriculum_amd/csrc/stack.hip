@@ -110,7 +110,7 @@ int alloc_work(Arena& a, Work& w, size_t MD, size_t MI, size_t delta_elems, size
     TRY(a.alloc(&w.ln_part, lnpart_elems));
     // Measured on MI355X (B=16): running the grouped dW launch on a side stream next to the dX chain gains nothing
     // (1398 vs 1419 clips/s) - each GEMM already holds all of a CU's LDS - so it is opt-in for experiments.
-    w.overlap = getenv("BVC_DW_OVERLAP") != nullptr;
+    w.overlap = false;      // bvc_set_option("dw_overlap", 1), read at every begin_backward
     BVC_CHECK_HIP(hipStreamCreateWithFlags(&w.side, hipStreamNonBlocking));
     BVC_CHECK_HIP(hipEventCreateWithFlags(&w.ev_fork, hipEventDisableTiming));
     BVC_CHECK_HIP(hipEventCreateWithFlags(&w.ev_join[0], hipEventDisableTiming));
@@ -125,6 +125,7 @@ void free_work(Work& w) {
 }
 
 void begin_backward(Work& w) {
+    w.overlap = options().dw_overlap != 0;
     w.seq = 0;
     w.join_pending[0] = w.join_pending[1] = false;
 }
@@ -153,8 +154,8 @@ int plan_dw(GemmProblem* g, int n) {
     // (tile x K split) as one stream of K tiles, so the split is chosen for ~230 units on the 256 CUs, at least 16 K tiles each.
     // Same-process A/B at 64 clips (profiles/r02_e_gemm8_ab_b64.txt): encoder layer 256 x 256 split 2 (216 units) 181 us vs
     // 256 x 128 unsplit 218 us vs the 128 x 128 kernel 220 us; decoder layer 256 x 256 split 6 (228 units) 549 us vs 626 us.
-    static const bool no_g8 = getenv("BVC_GEMM_NO_G8") != nullptr;
-    if (!no_g8) {
+    const int g8 = options().gemm8;
+    if (g8 >= 0) {
         bool ok = true;
         double flops = 0.0;
         for (int i = 0; i < n; ++i) {
@@ -163,6 +164,13 @@ int plan_dw(GemmProblem* g, int n) {
         }
         // short launches stay on the 128 x 128 kernel (at 16 clips: encoder layer 53 vs 85 us, decoder layer 139 vs 151 us,
         // profiles/r02_e_gemm8_ab_b16.txt): one workgroup per CU needs a long stream to amortise its prologue and tail
+        if (ok && g8 > 0 && ksteps >= 2) {          // forced (tests, A/B tools): 256 x 256 tiles, K split for ~230 units as below
+            int units = 0;
+            for (int i = 0; i < n; ++i) units += ((g[i].M + 255) / 256) * ((g[i].N + 255) / 256);
+            const int split = std::max(1, std::min((232 + units / 2) / units, ksteps / 2));
+            for (int i = 0; i < n; ++i) g[i].split_k = split;
+            return 10;
+        }
         if (ok && ksteps >= 16 && flops >= 140e9) {
             for (int t = 0; t < 2; ++t) {            // prefer the bigger tile when it still fills the chip
                 const int bnw = t == 0 ? 256 : 128;

@@ -142,7 +142,21 @@ int pixel_src(const void* pixels, const bvc_pixel_format* fmt, int channels, Pix
 extern "C" {
 
 const char* bvc_last_error(void) { return bvc::last_error(); }
-const char* bvc_version(void) { return "gfx950;bvc-hip-r1"; }
+const char* bvc_version(void) { return "gfx950;bvc-hip-r3"; }
+
+int bvc_set_option(const char* name, int value) {
+    BVC_REQUIRE(name != nullptr, "set_option: null name");
+    if (!strcmp(name, "gemm8")) { BVC_REQUIRE(value >= -1 && value <= 1, "set_option: gemm8 takes -1 / 0 / 1"); options().gemm8 = value; }
+    else if (!strcmp(name, "dw_overlap")) options().dw_overlap = value != 0;
+    else BVC_REQUIRE(false, "set_option: unknown option '%s'", name);
+    return BVC_OK;
+}
+int bvc_get_option(const char* name) {
+    if (name && !strcmp(name, "gemm8")) return options().gemm8;
+    if (name && !strcmp(name, "dw_overlap")) return options().dw_overlap;
+    bvc::set_error("get_option: unknown option '%s'", name ? name : "(null)");
+    return BVC_ERR_INVALID;
+}
 
 int bvc_videomae_param_count(const bvc_videomae_config* cfg) {
     if (!cfg || check_config(*cfg) != BVC_OK) return BVC_ERR_INVALID;
@@ -512,6 +526,21 @@ int bvc_op_gemm(const bvc_gemm_desc* problems, int count, int layout, int tile_c
     BVC_REQUIRE(layout >= 0 && layout <= 2, "op_gemm: bad layout %d", layout);
     return launch_gemm(problems, count, (GemmLayout)layout, tile_cfg, (hipStream_t)stream, stages);
 }
+int bvc_op_gemm_kernel(const bvc_gemm_desc* problems, int count, int layout, int tile_cfg, int stages, char* name, int name_cap) {
+    BVC_REQUIRE(problems && name && name_cap > 0, "op_gemm_kernel: null argument");
+    BVC_REQUIRE(layout >= 0 && layout <= 2, "op_gemm_kernel: bad layout %d", layout);
+    DryRun& d = dry_run();
+    d.on = true;
+    d.name[0] = 0;
+    const int rc = launch_gemm(problems, count, (GemmLayout)layout, tile_cfg, nullptr, stages);
+    d.on = false;
+    if (rc == BVC_OK) snprintf(name, name_cap, "%s", d.name);
+    return rc;
+}
+int bvc_op_gemm_plan_dw(bvc_gemm_desc* problems, int count) {
+    BVC_REQUIRE(problems && count >= 1 && count <= 4, "op_gemm_plan_dw: bad argument");
+    return plan_dw(problems, count);
+}
 int bvc_op_gemm_num_tiles(const bvc_gemm_desc* problem, int tile_cfg) {
     if (!problem) return BVC_ERR_INVALID;
     return gemm_num_tiles(*problem, tile_cfg);
@@ -525,6 +554,13 @@ int bvc_op_attention_bwd(const void* qkv, const void* ctx_in, const void* dctx, 
     BVC_REQUIRE(qkv && ctx_in && dctx && lse && delta && dqkv, "op_attention_bwd: null argument");
     return launch_attn_bwd((const bf16_t*)qkv, (const bf16_t*)ctx_in, (const bf16_t*)dctx, lse, delta, (bf16_t*)dqkv, B, N, H, head_dim,
                            (hipStream_t)stream);
+}
+int bvc_op_attention_bwd_part(const void* qkv, const void* ctx_in, const void* dctx, const float* lse, float* delta, void* dqkv,
+                              int B, int N, int H, int head_dim, int part, void* stream) {
+    BVC_REQUIRE(qkv && ctx_in && dctx && lse && delta && dqkv, "op_attention_bwd_part: null argument");
+    BVC_REQUIRE(part == 1 || part == 2, "op_attention_bwd_part: part is 1 (dQ + delta) or 2 (dK, dV)");
+    return launch_attn_bwd((const bf16_t*)qkv, (const bf16_t*)ctx_in, (const bf16_t*)dctx, lse, delta, (bf16_t*)dqkv, B, N, H, head_dim,
+                           (hipStream_t)stream, 0.f, part);
 }
 int bvc_op_layernorm_fwd(const float* x, int rin, int rout, int roff, const float* gamma, const float* beta, void* y,
                          float* mean, float* rstd, int M, int D, float eps, void* stream) {

@@ -52,39 +52,21 @@ def measured_traffic(batch):
         return None, None
 
 
-def dominant_kernel_probe(bvc, batch, device):
-    """The step's dominant kernel, timed alone with HIP events on the launch stream: the decoder fc1 product of one layer
-    (M = batch x 1568 tokens, K = 384, N = 1536, bias + exact GELU epilogue writing `pre` and `act`; four such launches per
-    step, the persistent GEMM kernel at this size).  Algorithmic FLOPs 2MNK and algorithmic bytes (A + W read, two bf16
-    outputs written) per launch over the measured launch time."""
-    ops = bvc._ops
-    M, N, K = batch * 1568, 1536, 384
-    g = torch.Generator(device="cpu").manual_seed(0)
-    A = torch.randn(M, K, generator=g).to(device).to(torch.bfloat16)
-    W = (torch.randn(N, K, generator=g) * 0.02).to(device).to(torch.bfloat16)
-    bias = torch.zeros(N, device=device)
-    pre = torch.empty(M, N, device=device, dtype=torch.bfloat16)
-    act = torch.empty_like(pre)
-    d = ops.gemm_desc(A, W, M, N, K, ops.EPI["GELU"], pre, C2=act, bias=bias)
-    for _ in range(3):
-        ops.gemm(d, ops.NT)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    iters = 20
-    e0.record()
-    for _ in range(iters):
-        ops.gemm(d, ops.NT)
-    e1.record()
-    torch.cuda.synchronize()
-    us = e0.elapsed_time(e1) * 1e3 / iters
-    flops, nbytes = 2.0 * M * N * K, 2.0 * (M * K + N * K + 2 * M * N)
-    t_mfma, t_hbm = flops / (PEAK_BF16_TFLOPS * 1e6), nbytes / (PEAK_HBM_GBS * 1e3)     # us at either roof
-    bound = "hbm" if t_hbm > t_mfma else "mfma"
-    return {"name": "decoder fc1 + bias + GELU (gemm8_kernel<256,NT> when >= 448 tiles, else gemm_persist_kernel<128,NT>)",
-            "shape": [M, N, K], "launch_us": round(us, 1), "launches_per_step": 4,
-            "achieved_tflops": round(flops / us / 1e6, 1), "frac_mfma": round(flops / us / 1e6 / PEAK_BF16_TFLOPS, 4),
-            "algorithmic_bytes": nbytes, "algorithmic_gb_per_s": round(nbytes / us / 1e3, 1),
-            "frac_hbm": round(nbytes / us / 1e3 / PEAK_HBM_GBS, 4), "bound": bound,
-            "frac": round(max(t_mfma, t_hbm) / us, 4)}
+def kernel_roofline(bvc, batch, device):
+    """Per-kernel roofline of the step, measured in this run (baby-vision-curriculum_amd/probe.py): every product / attention call /
+    LayerNorm of one step launched alone with HIP events on the launch stream, attributed to the kernel instantiation that runs it
+    (named as rocprofv3 names it).  The FIRST row is the step's dominant kernel; the decoder fc1 + GELU product (round 2's probe)
+    stays as `fc1_gelu`."""
+    rows, total_us = bvc.probe.step_kernels(batch, device)
+    top = rows[0]
+    fc1 = next((p for r in rows for p in r["products"] if p["name"] == "dec fc1+GELU"), None)
+    return {"kernel": top["kernel"], "launch_us": round(top["us_per_step"] / top["launches_per_step"], 1),
+            "kernel_launches_per_step": top["launches_per_step"], "kernel_us_per_step": top["us_per_step"],
+            "kernel_bound": top["bound"], "kernel_frac": top["frac"], "kernel_tflops": top["tflops"], "kernel_gb_per_s": top["gb_per_s"],
+            "kernel_products": top["products"],
+            "kernels": [{k: r[k] for k in ("kernel", "launches_per_step", "us_per_step", "share_of_probed", "tflops", "gb_per_s", "bound", "frac")}
+                        for r in rows[:10]],
+            "probed_us_per_step": round(total_us, 1), "fc1_gelu": fc1}
 
 
 def load_launcher():
@@ -152,6 +134,7 @@ def main():
                          "clips -> 0.15 / 0.20 / 0.21 / 0.22 of the MFMA roof) and 288 GB of HBM holds far more than the reference's "
                          "16 clips (slurm_dev_def.bash:52), so the default is 256 (~40 GB); BASELINE.md lists 16 and 64 as well")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-by-batch", action="store_true", help="skip the 64- and 16-clip legs reported as `by_batch`")
     ap.add_argument("--torch-sgd", action="store_true", help="use torch.optim.SGD instead of the fused HIP update")
     ap.add_argument("--per-step", action="store_true", help="diagnostic: per-step HIP-event and host-enqueue times to stderr")
     ap.add_argument("--bucket-mb", type=float, default=25.0, help="gradient all-reduce bucket size of the data-parallel wrapper")
@@ -220,6 +203,7 @@ def main():
     nstep = [0]
 
     def step():
+        # (B and clips are re-bound by the by_batch legs below)
         bool_masked = np.zeros((B, 1568))
         for i in range(B):
             bool_masked[i, :] = mask_gen()
@@ -277,6 +261,32 @@ def main():
     if use_ddp:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t)
+    # The same loop at the reference's per-GPU batch (16 clips, slurm_dev_def.bash:52) and at round 1's default (64), in the same
+    # run and the same line, so that rounds stay comparable whatever the headline batch is: 3 untimed + 10 timed steps each.
+    by_batch = {}
+    if world == 1 and not args.stream_input and not args.no_by_batch:
+        full = clips
+        for b in (64, 16):
+            if b >= B:
+                continue
+            clips, B = full[:b], b
+            for _ in range(3):
+                step()
+            f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            w0 = time.perf_counter()
+            f0.record()
+            for _ in range(10):
+                step()
+            f1.record()
+            torch.cuda.synchronize()
+            wall = time.perf_counter() - w0
+            ms = f0.elapsed_time(f1) / 10
+            tf = GFLOP_PER_CLIP * 1e9 * b / (ms * 1e-3) / 1e12
+            tr, _src = measured_traffic(b)
+            by_batch[str(b)] = {"value": round(b * 10 / wall, 2), "unit": "clips/s", "ms_per_step": round(1e3 * wall / 10, 4), "steps": 10,
+                                "roofline": {"bound": "mfma", "achieved": round(tf, 2), "frac": round(tf / PEAK_BF16_TFLOPS, 4), "traffic": tr}}
+        clips, B = full, args.batch
     comm = None
     if use_ddp:
         # two more steps OUTSIDE the timed region with per-bucket events on the communication stream: bytes, time, ring bus bandwidth
@@ -315,11 +325,11 @@ def main():
                          "flops_per_launch": GFLOP_PER_CLIP * 1e9 * B, "launch_ms": round(step_ms_gpu, 4)},
         }
         if world == 1:
-            # the dominant kernel of the step, timed alone in this run: named at the top level of `roofline`, with the bound its
-            # own numbers say (fc1 + GELU at K = 384 writes two M x 1536 bf16 outputs: HBM-bound, not MFMA-bound)
-            dk = dominant_kernel_probe(bvc, B, dev)
-            line["roofline"].update({"kernel": dk["name"], "launch_us": dk["launch_us"], "kernel_bound": dk["bound"],
-                                     "kernel_frac": dk["frac"], "dominant_kernel": dk})
+            # the dominant kernel of the step = the kernel instantiation with the largest time share, from per-product launches
+            # timed alone in this run and named as rocprofv3 names them (compare: profiles/r03_*_roofline_table_b256.txt row 1)
+            line["roofline"].update(kernel_roofline(bvc, B, dev))
+            if by_batch:
+                line["by_batch"] = by_batch
         if comm is not None:
             line["comm"] = comm
         if stream_info is not None:

@@ -35,6 +35,15 @@ extern "C" {
 const char* bvc_last_error(void);
 /* Library build info: "gfx950;<git-less build tag>" */
 const char* bvc_version(void);
+/* Process-wide kernel-selection switches (the reference has no counterpart: ATen picks its cuBLAS kernels by itself).  They
+ * exist for the parity tests and the same-process A/B tools, never change results beyond the documented tolerances, and
+ * replace the environment variables earlier builds read:
+ *   "gemm8"       0 (default) = the measured selection; 1 = the 256-row persistent GEMM for every product it can take,
+ *                 whatever its size (runs the kernel set of the 256-clip benchmark at oracle-sized batches); -1 = never
+ *   "dw_overlap"  1 = a layer's grouped weight-gradient launch runs on the context's side stream (default 0)
+ * bvc_get_option returns the value, or BVC_ERR_INVALID for an unknown name. */
+int bvc_set_option(const char* name, int value);
+int bvc_get_option(const char* name);
 
 /* ------------------------------------------------------------------------------------------------
  * VideoMAE pre-training step.
@@ -226,12 +235,21 @@ typedef struct bvc_gemm_desc {
  * (3-5 and 8 are experiment kernels that exist only in a -DBVC_EXPERIMENTS build.)  stages: -1 auto, 2..4 = K-loop variant. */
 int bvc_op_gemm(const bvc_gemm_desc* problems, int count, int layout, int tile_cfg, int stages, void* stream);
 int bvc_op_gemm_num_tiles(const bvc_gemm_desc* problem, int tile_cfg);
+/* Introspection of the selection above, nothing is launched: the kernel instantiation bvc_op_gemm would run for these problems,
+ * named as rocprofv3 prints it (e.g. "bvc::gemm8_kernel<256, true, true, 2>"), so that per-product timings can be attributed to the
+ * rows of a kernel-stats table (bench.py's `roofline.kernels`); and the (tile_cfg, split_k) plan the step uses for a group of
+ * weight-gradient products (returns the tile config, writes split_k into the descriptors). */
+int bvc_op_gemm_kernel(const bvc_gemm_desc* problems, int count, int layout, int tile_cfg, int stages, char* name, int name_cap);
+int bvc_op_gemm_plan_dw(bvc_gemm_desc* problems, int count);
 
 /* softmax(QK^T/sqrt(d))V for head_dim d = 64 or 32; qkv bf16 [B*N][3*d*H]; replaces HF:181-206 / SDPA (HF:239-252) and
  * Attention.forward of pretraining/predictive/vision_transformer.py:198-210 (the ViT-B predictor has d = 32) */
 int bvc_op_attention_fwd(const void* qkv, void* ctx_out, float* lse, int B, int N, int H, int head_dim, void* stream);
 int bvc_op_attention_bwd(const void* qkv, const void* ctx_in, const void* dctx, const float* lse, float* delta_scratch,
                          void* dqkv, int B, int N, int H, int head_dim, void* stream);
+/* one of the backward's two kernels alone (timing probes): part 1 = dQ (+ delta_scratch), part 2 = dK / dV (reads delta_scratch) */
+int bvc_op_attention_bwd_part(const void* qkv, const void* ctx_in, const void* dctx, const float* lse, float* delta_scratch,
+                              void* dqkv, int B, int N, int H, int head_dim, int part, void* stream);
 /* nn.LayerNorm forward/backward (HF:336-337,484); rows may be strided by (rin, rout, roff), rin<=0 = dense */
 int bvc_op_layernorm_fwd(const float* x, int rin, int rout, int roff, const float* gamma, const float* beta, void* y_bf16,
                          float* mean, float* rstd, int M, int D, float eps, void* stream);

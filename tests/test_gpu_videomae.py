@@ -118,7 +118,7 @@ def test_base_step_matches_oracle_and_fixture(golden_dir, case):
     _check_step(case, vo.BASE, fx["batch"], fx["seed"], fx["mask_ratio"], wseed=fx["weight_seed"], fixture=fx)
 
 
-def test_base_b16_matches_transformers_fixture(golden_dir):
+def test_base_b16_matches_transformers_fixture(golden_dir, tag="base_b16_s0"):
     """The reference's own per-GPU batch (slurm_dev_def.bash:52): VideoMAE-base, 16 clips, against the numbers transformers 5.15.0
     produced in the build container (tests/golden/videomae_base_b16_s0.json): loss, the three grad_logger probes (1e-3, the
     north_star bar) and the L2 norm of every one of the 264 gradient tensors (2e-2; norms only - the fixture holds no tensors)."""
@@ -134,13 +134,13 @@ def test_base_b16_matches_transformers_fixture(golden_dir):
     torch.cuda.synchronize()
     loss = float(out.loss)
     rel = abs(loss - fx["loss"]) / fx["loss"]
-    _log(f"[base_b16_s0] loss hip {loss:.7f} transformers {fx['loss']:.7f} rel {rel:.2e}")
+    _log(f"[{tag}] loss hip {loss:.7f} transformers {fx['loss']:.7f} rel {rel:.2e}")
     assert rel < 1e-3
     named = dict(model.named_parameters())
     for k in vo.GRAD_PROBES:
         gn, rn = float(named[k].grad.norm()), fx["grad_probes"][k]
         e = abs(gn - rn) / rn
-        _log(f"[base_b16_s0] grad-norm {k}: hip {gn:.6e} transformers {rn:.6e} rel {e:.2e} (bar 1e-3, margin {1e-3 / max(e, 1e-12):.1f}x)")
+        _log(f"[{tag}] grad-norm {k}: hip {gn:.6e} transformers {rn:.6e} rel {e:.2e} (bar 1e-3, margin {1e-3 / max(e, 1e-12):.1f}x)")
         assert e < 1e-3, (k, e)
     gmax = max(fx["grad_l2"].values())
     worst = ("", 0.0)
@@ -151,13 +151,40 @@ def test_base_b16_matches_transformers_fixture(golden_dir):
         if e > worst[1]:
             worst = (k, e)
         assert e < 2e-2, (k, gn, rn)
-    _log(f"[base_b16_s0] worst per-tensor gradient-norm rel {worst[1]:.2e} ({worst[0]}) over {len(named)} tensors")
+    _log(f"[{tag}] worst per-tensor gradient-norm rel {worst[1]:.2e} ({worst[0]}) over {len(named)} tensors")
 
 
-@pytest.mark.parametrize("nb", [16, 64])
+@pytest.fixture
+def forced_gemm8():
+    """bvc_set_option("gemm8", 1): every product the 256-row persistent kernel can take runs on it, whatever its size - the kernel
+    set of the 256-clip benchmark (gemm8_kernel<256 / 128, NT / NN / TN> in all four epilogue classes, the split-K weight-gradient
+    groups) at batches the oracle and the transformers fixtures exist for.  Restored afterwards."""
+    old = G.L.set_option("gemm8", 1)
+    yield
+    G.L.set_option("gemm8", old)
+
+
+def test_base_step_matches_oracle_and_fixture_on_gemm8(golden_dir, forced_gemm8):
+    """Oracle parity of the kernel set bench.py runs (at 2 / 16 clips the measured selection never picks gemm8: every launch is
+    below its 45-GFLOP gate)."""
+    with open(os.path.join(golden_dir, "videomae_base_b2_s0.json")) as f:
+        fx = json.load(f)
+    _check_step("base_b2_s0_gemm8", vo.BASE, fx["batch"], fx["seed"], fx["mask_ratio"], wseed=fx["weight_seed"], fixture=fx)
+
+
+def test_base_b16_matches_transformers_fixture_on_gemm8(golden_dir, forced_gemm8):
+    test_base_b16_matches_transformers_fixture(golden_dir, tag="base_b16_s0_gemm8")
+
+
+def test_tiny_step_on_gemm8(forced_gemm8):
+    # ragged everything: 64-wide model on 256-wide tiles, 3 clips
+    _check_step("tiny_s1_gemm8", vo.TINY, 3, 1, 0.75, wseed=1, grad_scale=65536.0)
+
+
+@pytest.mark.parametrize("nb", [16, 64, 256])
 def test_full_batch_properties(nb):
-    """BASELINE batches (16 clips = the reference's slurm default, 64 = bench.py's default): size-independent properties
-    instead of a full-batch CPU run."""
+    """BASELINE batches (16 clips = the reference's slurm default, 64 = round 1's bench default, 256 = bench.py's default):
+    size-independent properties instead of a full-batch CPU run."""
     cfg = vo.BASE
     params = vo.make_params(cfg, seed=0)
     pixels, mask = vo.synthetic_batch(cfg, nb, seed=11, mask_ratio=0.9)

@@ -1,5 +1,5 @@
-"""Same-process A/B of the 256-row persistent GEMM (csrc/gemm8.hip, tile configs 10 / 11) against the product path ("auto":
-128 x 128 per-tile / persistent kernels) on every product of the VideoMAE-base step at BVC_BATCH clips.  Interleaved rounds,
+"""Same-process A/B of the 256-row persistent GEMM (csrc/gemm8.hip, tile configs 10 / 11) against the 128 x 128 per-tile /
+persistent kernels ("auto" with bvc_set_option("gemm8", -1)) on every product of the VideoMAE-base step at BVC_BATCH clips.  Interleaved rounds,
 median of the per-round times (HIP events on the launch stream)."""
 import os
 import statistics
@@ -25,6 +25,7 @@ def time_once(fn, iters):
 
 
 def main():
+    G.L.set_option("gemm8", -1)       # "auto" below = the selection WITHOUT the 256-row kernel; tiles 10 / 11 name it explicitly
     Bc = int(os.environ.get("BVC_BATCH", "64"))
     Me, Md, Mm = Bc * 160, Bc * 1568, Bc * 1408
     cases = [

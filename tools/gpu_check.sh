@@ -50,7 +50,7 @@ PY
               ;;
     ops)   run ops 420 python -m pytest tests/test_gpu_ops.py -m gpu -q -p no:cacheprovider ;;
     model) run model 420 python -m pytest tests/test_gpu_videomae.py -m gpu -q -p no:cacheprovider ;;
-    all)   run alltests 600 python -m pytest tests -m gpu -q -x -p no:cacheprovider ;;
+    all)   run alltests 900 python -m pytest tests -m gpu -q -x -p no:cacheprovider ;;
     smoke) run smoke 200 python -c "import __graft_entry__ as g; g.smoke()" ;;
     bench) run bench 400 python bench.py ;;
     bench32) run bench32 400 python bench.py --batch 32 --no-cpu-baseline ;;
@@ -62,9 +62,9 @@ PY
     bench64) run bench64 400 python bench.py --batch 64 --no-cpu-baseline --steps 15 ;;
     benchq) run benchq 300 python bench.py --no-cpu-baseline ;;
     benchddp) BVC_FORCE_DDP=1 run benchddp 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --steps 20 --warmup 3 --no-cpu-baseline ;;
-    benchov) BVC_DW_OVERLAP=1 run benchov 300 python bench.py --no-cpu-baseline ;;
     micro) run micro 400 python tools/microbench.py ;;
     racescreen) run racescreen 500 python tools/persist_race_screen.py ;;
+    g8race) run g8race 600 python tools/g8_race_screen.py ;;
     gemmdbg) run gemmdbg 300 python tools/gemm_dbg.py ;;
     ksweep) run ksweep 400 python tools/gemm_ksweep.py ;;
     dwsweep) run dwsweep 400 python tools/dw_sweep.py ;;

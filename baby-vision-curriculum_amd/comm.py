@@ -1,14 +1,21 @@
 """The library's RCCL communicator (include/bvc.h "communication") for the ranks of a torch.distributed job.
 
 The reference's entry points create the process group themselves (dist.init_process_group("nccl", ...),
-pretraining/generative/pretrain_videomae.py:87-90) and every collective of the step then goes through it.  Here the step's
-collectives - gradient buckets during backward, the SimCLR embedding all-gather - run on a communicator the library owns
-(its own communication stream and event fences, no Python between a bucket's last kernel and its all-reduce); the process
-group the script initialised is used once, to hand rank 0's 128-byte RCCL id to the other ranks, and for a one-off
-cross-check of the new communicator against it.
+pretraining/generative/pretrain_videomae.py:87-90) and every collective of the step then goes through it.
 
-`get(device)` returns the communicator of this process, or None when the job is not on RCCL (gloo on CPU, no process group):
-callers then stay on torch.distributed.  BVC_COMM=torch forces that too (A/B of the two paths on one box).
+ONE communicator carries every collective of a step, whichever it is:
+  * default: the process group the script initialised (torch.distributed, "nccl" = RCCL) - gradient buckets on a side stream,
+    the loss all-reduce, the module-state broadcast, the SimCLR all-gather;
+  * BVC_COMM=bvc (opt-in): the communicator the LIBRARY owns (include/bvc.h "communication": its own communication stream and
+    event fences, no Python between a bucket's last kernel and its all-reduce).  Then all of the above go through it - buckets
+    (bvc_allreduce_bucket), loss scalar and all-gather backward (bvc_allreduce), module-state sync (bvc_broadcast), all-gather
+    (bvc_allgather), every one of them on the library's communication stream in program order - and the script's process group
+    is used for two things only: handing rank 0's 128-byte RCCL id to the other ranks, and barriers outside the step.
+    It is opt-in because no run with more than one rank on GPUs has been recorded yet (the builder's boxes have one GPU):
+    multi-rank behaviour of this path is unpinned; the one-rank RCCL tests and the one-GPU rehearsal cover its plumbing.
+
+`get(device)` returns the library's communicator, or None (callers then use torch.distributed) when it was not asked for, or
+when the job is not on RCCL (gloo on CPU, no process group).
 """
 from __future__ import annotations
 
@@ -70,30 +77,57 @@ class Communicator:
             self.handle = None
 
 
+def _agreed(flag, device):
+    """True iff `flag` holds on EVERY rank (one small all-reduce on the script's process group)."""
+    t = torch.tensor([1.0 if flag else 0.0], device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return float(t) >= 1.0
+
+
 def _create(device):
+    """Collective over the process group: every rank makes the same sequence of torch.distributed calls whatever fails where
+    (agree on rank 0's id -> broadcast it -> init -> probe), so a failure on one rank can never leave the others in a different
+    collective.  Returns the communicator, or raises on the ranks where a step failed (get() then agrees on all-or-none)."""
     rank, world = dist.get_rank(), dist.get_world_size()
     lib = _lib.lib()
     ident = torch.zeros(128, dtype=torch.uint8)
+    id_err = None
     if rank == 0:
-        buf = (ctypes.c_uint8 * 128)()
-        _lib.check(lib.bvc_comm_unique_id(buf), "bvc_comm_unique_id")
-        ident = torch.tensor(list(buf), dtype=torch.uint8)
+        try:
+            buf = (ctypes.c_uint8 * 128)()
+            _lib.check(lib.bvc_comm_unique_id(buf), "bvc_comm_unique_id")
+            ident = torch.tensor(list(buf), dtype=torch.uint8)
+        except Exception as e:      # noqa: BLE001
+            id_err = e
+    # rank 0's status first: without this, a rank 0 that failed above would skip the broadcast its peers are waiting in
+    if not _agreed(id_err is None, device):
+        raise _lib.BvcError(f"rank 0 could not create an RCCL id ({id_err or 'see rank 0'})")
     ident = ident.to(device)
     dist.broadcast(ident, src=0)                        # the side channel: the script's own process group
     raw = bytes(ident.cpu().tolist())
     handle = ctypes.c_void_p()
-    with torch.cuda.device(device):
-        _lib.check(lib.bvc_comm_init(rank, world, ctypes.c_char_p(raw), ctypes.byref(handle)), "bvc_comm_init")
+    init_err = None
+    try:
+        with torch.cuda.device(device):
+            _lib.check(lib.bvc_comm_init(rank, world, ctypes.c_char_p(raw), ctypes.byref(handle)), "bvc_comm_init")
+    except Exception as e:          # noqa: BLE001
+        init_err = e
+    if not _agreed(init_err is None, device):
+        if init_err is None:
+            lib.bvc_comm_destroy(handle)
+        raise _lib.BvcError(f"bvc_comm_init failed on at least one rank ({init_err or 'another rank'})")
     c = Communicator(handle, rank, world, device)
-    # cross-check against the process group before anything depends on it: mean of (rank + 1) over ranks, and an all-gather
+    # cross-check against the process group before anything depends on it: mean of (rank + 1) over ranks, and an all-gather.
+    # The two communicators never have work in flight together: each side is drained before the other is used.
     probe = torch.full((1024,), float(rank + 1), device=device)
     c.allreduce_bucket(probe, average=True)
     c.wait()
+    gathered = torch.empty(world * 4, device=device)
+    c.allgather(torch.full((4,), float(rank), device=device), gathered)
+    torch.cuda.synchronize(device)
     ref = torch.full((1024,), float(rank + 1), device=device)
     dist.all_reduce(ref, op=dist.ReduceOp.SUM)
     ref /= world
-    gathered = torch.empty(world * 4, device=device)
-    c.allgather(torch.full((4,), float(rank), device=device), gathered)
     want = torch.arange(world, device=device, dtype=torch.float32).repeat_interleave(4)
     if not (torch.allclose(probe, ref) and torch.equal(gathered, want)):
         c.close()
@@ -101,37 +135,40 @@ def _create(device):
     return c
 
 
+def requested():
+    """Was the library's communicator asked for?  BVC_COMM=bvc; the default (and BVC_COMM=torch) is torch.distributed."""
+    return os.environ.get("BVC_COMM", "") == "bvc"
+
+
 def get(device=None):
-    """This process's communicator on `device`, created on first use; None when torch.distributed is not running on RCCL."""
+    """This process's library communicator on `device`, created on first use; None when it was not requested (BVC_COMM=bvc) or
+    torch.distributed is not running on RCCL.  Creation is collective: call it at the same point on every rank (the data-parallel
+    wrapper's constructor does)."""
     global _comm, _tried
     if _comm is not None and (not (dist.is_available() and dist.is_initialized()) or
                               (dist.get_rank(), dist.get_world_size()) != (_comm.rank, _comm.world)):
         reset()          # the process group it was created for is gone (destroy_process_group / a new init): never reuse it
     if _comm is not None or _tried:
         return _comm
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_backend() != "nccl" or not torch.cuda.is_available():
+    if not requested():
         return None
-    if os.environ.get("BVC_COMM", "") == "torch":
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_backend() != "nccl" or not torch.cuda.is_available():
         return None
     _tried = True
     device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-    def agreed(flag):
-        t = torch.tensor([1.0 if flag else 0.0], device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MIN)
-        return float(t) >= 1.0
 
     # before anyone enters ncclCommInitRank (which waits for every rank): can each rank reach an RCCL library at all?
     where = _lib.lib().bvc_comm_library().decode()
-    if not agreed("librccl" in where and "[" not in where):
+    if not _agreed("librccl" in where and "[" not in where, device):
         warnings.warn(f"bvc communicator unavailable (RCCL: {where}); the step's collectives stay on torch.distributed")
         return None
     err = None
     try:
         made = _create(device)
-    except Exception as e:
+    except Exception as e:          # noqa: BLE001
         made, err = None, e
     # all ranks or none: a rank that failed alone would otherwise leave the others waiting in their first bucket
-    if not agreed(made is not None):
+    if not _agreed(made is not None, device):
         if made is not None:
             made.close()
         warnings.warn(f"bvc communicator unavailable on at least one rank ({err or 'another rank failed'}); "

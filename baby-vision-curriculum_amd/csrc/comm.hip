@@ -198,28 +198,51 @@ int bvc_comm_wait(bvc_comm* c, void* stream) {
     return BVC_OK;
 }
 
-// recv[r * bytes_per_rank ...] = rank r's send buffer, for every r; runs ON `stream` (the gathered rows are consumed next).
+// The three collectives below are consumed by the caller's very next kernels, yet they run on the COMMUNICATION stream like the
+// buckets do: one communicator is then driven from one stream only, in program order (RCCL executes a communicator's operations in
+// issue order; issuing them from two streams adds nothing but the chance of a cross-stream wait cycle).  hop_in orders the
+// communication stream behind everything enqueued on the caller's stream, hop_out orders the caller's stream behind the collective.
+static int hop_in(bvc_comm* c, hipStream_t s) {
+    if (s == c->stream) return BVC_OK;
+    hipEvent_t ev = c->fence[c->next_fence];
+    c->next_fence = (c->next_fence + 1) % bvc_comm::kFences;
+    BVC_CHECK_HIP(hipEventRecord(ev, s));
+    BVC_CHECK_HIP(hipStreamWaitEvent(c->stream, ev, 0));
+    return BVC_OK;
+}
+static int hop_out(bvc_comm* c, hipStream_t s) {
+    if (s == c->stream) return BVC_OK;
+    BVC_CHECK_HIP(hipEventRecord(c->tail, c->stream));
+    BVC_CHECK_HIP(hipStreamWaitEvent(s, c->tail, 0));
+    return BVC_OK;
+}
+
+// recv[r * bytes_per_rank ...] = rank r's send buffer, for every r; ordered after `stream`, `stream` continues after it.
 int bvc_allgather(bvc_comm* c, const void* send, void* recv, int64_t bytes_per_rank, void* stream) {
     BVC_REQUIRE(c && c->comm, "allgather: no communicator");
     BVC_REQUIRE(send && recv && bytes_per_rank > 0, "allgather: empty buffer");
-    BVC_CHECK_NCCL(bvc::rccl().AllGather(send, recv, (size_t)bytes_per_rank, ncclUint8, c->comm, (hipStream_t)stream));
-    return BVC_OK;
+    if (int rc = hop_in(c, (hipStream_t)stream)) return rc;
+    BVC_CHECK_NCCL(bvc::rccl().AllGather(send, recv, (size_t)bytes_per_rank, ncclUint8, c->comm, c->stream));
+    return hop_out(c, (hipStream_t)stream);
 }
 
-// In-place sum over ranks of count f32 ON `stream` (the backward of the all-gather: sum, then the caller keeps its own rows).
+// In-place sum / mean over ranks of count f32 (the backward of the all-gather: sum, then the caller keeps its own rows; the loss
+// scalar, which thereby follows the step's last gradient bucket on the communication stream).
 int bvc_allreduce(bvc_comm* c, float* buf, int64_t count, int average, void* stream) {
     BVC_REQUIRE(c && c->comm, "allreduce: no communicator");
     BVC_REQUIRE(buf != nullptr && count > 0, "allreduce: empty buffer");
-    BVC_CHECK_NCCL(bvc::rccl().AllReduce(buf, buf, (size_t)count, ncclFloat32, average ? ncclAvg : ncclSum, c->comm, (hipStream_t)stream));
-    return BVC_OK;
+    if (int rc = hop_in(c, (hipStream_t)stream)) return rc;
+    BVC_CHECK_NCCL(bvc::rccl().AllReduce(buf, buf, (size_t)count, ncclFloat32, average ? ncclAvg : ncclSum, c->comm, c->stream));
+    return hop_out(c, (hipStream_t)stream);
 }
 
-// buf of root -> buf of every rank, ON `stream` (the module-state sync at wrap time).
+// buf of root -> buf of every rank (the module-state sync at wrap time).
 int bvc_broadcast(bvc_comm* c, void* buf, int64_t bytes, int root, void* stream) {
     BVC_REQUIRE(c && c->comm, "broadcast: no communicator");
     BVC_REQUIRE(buf != nullptr && bytes > 0 && root >= 0 && root < c->world, "broadcast: bad argument");
-    BVC_CHECK_NCCL(bvc::rccl().Broadcast(buf, buf, (size_t)bytes, ncclUint8, root, c->comm, (hipStream_t)stream));
-    return BVC_OK;
+    if (int rc = hop_in(c, (hipStream_t)stream)) return rc;
+    BVC_CHECK_NCCL(bvc::rccl().Broadcast(buf, buf, (size_t)bytes, ncclUint8, root, c->comm, c->stream));
+    return hop_out(c, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -68,6 +68,16 @@ class DistributedDataParallel(nn.Module):
         self._device = None
         if device_ids:
             self._device = torch.device("cuda", device_ids[0]) if isinstance(device_ids[0], int) else torch.device(device_ids[0])
+        else:
+            # DDP(encoder, static_graph=True) - no device_ids, the reference's JEPA form (pretrain_jepa.py:302-304): the device the
+            # module already lives on, else (a module still on the CPU in an RCCL job) this process's current GPU.  Everything that
+            # needs a rendezvous - flat buffers, the library communicator - is then set up HERE, never inside the first backward.
+            devs = {p.device for p in module.parameters()} if isinstance(module, nn.Module) else set()
+            cuda = [d for d in devs if d.type == "cuda"]
+            if cuda:
+                self._device = cuda[0]
+            elif dist.get_backend(process_group) == "nccl" and torch.cuda.is_available():
+                self._device = torch.device("cuda", torch.cuda.current_device())
 
         # flat modules inside `module` (itself included) and the parameters that belong to none of them
         mods = list(module.modules()) if isinstance(module, nn.Module) else [module]
@@ -82,6 +92,7 @@ class DistributedDataParallel(nn.Module):
         self._loose = [p for p in module.parameters() if id(p) not in owned] if isinstance(module, nn.Module) else []
         self._loose_grad = [p for p in self._loose if p.requires_grad]
         self._loose_seen = 0
+        self._loose_flush_queued = False
         if self._device is not None and self._device.type == "cuda":
             self._native_comm(self._device)       # create the library communicator now (rendezvous + probe), not inside the first backward
         if broadcast_parameters:
@@ -97,15 +108,23 @@ class DistributedDataParallel(nn.Module):
         return self._flats[0].reduced_ranges if self._flats else []
 
     # module-state sync from rank 0, what DDP's constructor does (C2 in SURVEY.md 2.3)
+    def _bcast(self, t):
+        """rank 0's tensor to every rank, on the step's communicator (comm.py: bvc_broadcast when the library's was requested)."""
+        nc = self._native_comm(t.device) if t.is_cuda else None
+        if nc is not None:
+            nc.broadcast(t, root=0)
+        else:
+            dist.broadcast(t, src=0, group=self.process_group)
+
     def _broadcast(self):
         for st in self._flats:
-            dist.broadcast(st.module.flat_parameters(), src=0, group=self.process_group)
+            self._bcast(st.module.flat_parameters())
         tensors = [p.data for p in self._loose]
         if isinstance(self.module, nn.Module):
             tensors += [b.data for b in self.module.buffers() if b.is_floating_point()]
         if tensors:
             flat = torch.cat([t.reshape(-1).float() for t in tensors])
-            dist.broadcast(flat, src=0, group=self.process_group)
+            self._bcast(flat)
             o = 0
             for t in tensors:
                 n = t.numel()
@@ -113,6 +132,8 @@ class DistributedDataParallel(nn.Module):
                 o += n
 
     def forward(self, *args, **kwargs):
+        self._loose_seen = 0          # a backward that ended early (exception, a parameter without gradient) must not shift the next one
+        self._loose_flush_queued = False
         return self.module(*args, **kwargs)
 
     # ---- gradient exchange
@@ -218,14 +239,23 @@ class DistributedDataParallel(nn.Module):
             self._timed = []
 
     def _on_loose_grad(self, _param):
-        """autograd has accumulated one more ordinary parameter; after the last one, average them all as ONE collective."""
+        """autograd has accumulated one more ordinary parameter.  The coalesced all-reduce of all of them runs ONCE per backward,
+        from an end-of-backward callback of the autograd engine: it does not depend on an exact count of hook firings (a parameter
+        that received no gradient in this backward, or whose requires_grad was toggled after wrapping, would make a counter fire
+        at the wrong moment - or on some ranks only, which is a hang)."""
         self._loose_seen += 1
-        if self._loose_seen < len(self._loose_grad):
-            return
+        if not self._loose_flush_queued:
+            self._loose_flush_queued = True
+            torch.autograd.Variable._execution_engine.queue_callback(self._flush_loose)
+
+    def _flush_loose(self):
+        self._loose_flush_queued = False
         self._loose_seen = 0
         if not self._active():
             return
-        grads = [p.grad for p in self._loose_grad if p.grad is not None]
+        # every rank reduces the SAME list - all parameters that may receive gradients, zeros standing in for the ones this
+        # backward did not reach - so the collective's size never depends on rank-local control flow
+        grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in self._loose_grad]
         if not grads:
             return
         flat = torch.cat([g.reshape(-1).float() for g in grads])
@@ -233,9 +263,10 @@ class DistributedDataParallel(nn.Module):
         if flat.is_cuda:
             self._join(flat.device)      # a few MB: not worth overlapping, and the copies below read it
         o = 0
-        for g in grads:
+        for p, g in zip(self._loose_grad, grads):
             n = g.numel()
-            g.copy_(flat[o:o + n].view_as(g))
+            if p.grad is not None:
+                p.grad.copy_(flat[o:o + n].view_as(g))
             o += n
 
     # ---- reporting (bench.py): algorithm bandwidth and ring bus bandwidth per bucket of the logged backwards

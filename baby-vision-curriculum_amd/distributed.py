@@ -1,4 +1,5 @@
-"""Collectives of the training step as autograd nodes, over torch.distributed ("nccl" = RCCL on ROCm, gloo on CPU).
+"""Collectives of the training step as autograd nodes, over the step's ONE communicator (comm.py): the script's process group
+(torch.distributed: "nccl" = RCCL on ROCm, gloo on CPU) or, with BVC_COMM=bvc, the library's own RCCL communicator.
 
 What the reference's entry points expect from them (interfaces only; the bodies below are this package's):
   AllReduce     pretraining/generative/ddputils.py:53-68, pretraining/predictive/distributed.py:96-112
@@ -24,7 +25,13 @@ def world():
 def _reduced(t, scale):
     """Sum of `t * scale` over all ranks, as a new tensor (the collective works in place on a private copy)."""
     buf = (t * scale).contiguous() if scale != 1.0 else t.contiguous().clone()
-    dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+    nc = _comm.get(buf.device) if buf.is_cuda and buf.dtype == torch.float32 and buf.numel() > 0 else None
+    if nc is not None:
+        # bvc_allreduce: on the library's communication stream, behind the gradient buckets already enqueued there (the loss
+        # scalar of AllReduce follows the step's last bucket), the current stream continues after it
+        nc.allreduce(buf.view(-1), average=False)
+    else:
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM)
     return buf
 
 
@@ -81,10 +88,5 @@ class AllGather(torch.autograd.Function):
         start, rows, n = ctx.span
         if n == 1:
             return grad_output
-        nc = _comm.get(grad_output.device) if grad_output.is_cuda and grad_output.dtype == torch.float32 else None
-        if nc is not None:
-            total = grad_output.contiguous().clone()
-            nc.allreduce(total, average=False)
-        else:
-            total = _reduced(grad_output, 1.0)
+        total = _reduced(grad_output, 1.0)
         return total.narrow(0, start, rows)

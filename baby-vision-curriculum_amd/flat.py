@@ -149,10 +149,28 @@ class FlatParamModule(nn.Module):
             self._after_backward()
 
     def _bucket_callback(self, accumulate):
+        """The bvc_bucket_fn handed to bvc_*_backward.  It runs INSIDE the library call, as a ctypes callback: Python would print an
+        exception raised there and carry on - a rank whose bucket all-reduce (or communicator creation) failed would step its
+        optimiser on unreduced gradients while its peers wait in the collective.  So the callback catches, keeps the first
+        exception and ignores every later range of that backward; `_library_backward` re-raises it as soon as the call returns,
+        before any gradient is published."""
+        self._cb_error = None
         hook = self._bucket_hook if not accumulate else None
         if hook is None:
             return ctypes.cast(None, _lib.BUCKET_FN)
 
         def _cb(offset, count, _user, _hook=hook):
-            _hook(int(offset), int(count))
+            if self._cb_error is not None:
+                return
+            try:
+                _hook(int(offset), int(count))
+            except BaseException as e:      # noqa: BLE001 - nothing may escape into the C caller
+                self._cb_error = e
         return _lib.BUCKET_FN(_cb)
+
+    def _library_backward(self, what, rc):
+        """Status check of a bvc_*_backward call that was given `_bucket_callback`: an exception kept by the callback wins."""
+        err, self._cb_error = getattr(self, "_cb_error", None), None
+        if err is not None:
+            raise err
+        _lib.check(rc, what)

@@ -184,8 +184,8 @@ class VisionTransformer(FlatParamModule):
         target, accumulate = self._grad_target()
         d = dout.detach().to(torch.float32).contiguous()
         cb = self._bucket_callback(accumulate)
-        _lib.check(_lib.lib().bvc_vit_backward(self._ctx, d.data_ptr(), target.data_ptr(), cb, None, _lib.current_stream_ptr()),
-                   "bvc_vit_backward")
+        self._library_backward("bvc_vit_backward",
+                               _lib.lib().bvc_vit_backward(self._ctx, d.data_ptr(), target.data_ptr(), cb, None, _lib.current_stream_ptr()))
         self._publish_grads(target, accumulate)
         self._live = None
 
@@ -301,8 +301,9 @@ class VisionTransformerPredictor(FlatParamModule):
         d = dout.detach().to(torch.float32).contiguous()
         dz = torch.empty_like(zf)
         cb = self._bucket_callback(accumulate)      # per-block gradient ranges, tail first, for the data-parallel wrapper
-        _lib.check(_lib.lib().bvc_predictor_backward_cb(self._ctx, d.data_ptr(), target.data_ptr(), dz.data_ptr(), cb, None,
-                                                        _lib.current_stream_ptr()), "bvc_predictor_backward")
+        self._library_backward("bvc_predictor_backward",
+                               _lib.lib().bvc_predictor_backward_cb(self._ctx, d.data_ptr(), target.data_ptr(), dz.data_ptr(), cb, None,
+                                                                    _lib.current_stream_ptr()))
         self._publish_grads(target, accumulate)
         self._live = None
         return dz

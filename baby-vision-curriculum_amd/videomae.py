@@ -198,8 +198,8 @@ class VideoMAEForPreTraining(FlatParamModule):
         target, accumulate = self._grad_target()
         g = grad_loss.detach().to(dtype=torch.float32).contiguous()
         cb = self._bucket_callback(accumulate)
-        _lib.check(_lib.lib().bvc_videomae_backward(self._ctx, g.data_ptr(), target.data_ptr(), cb, None,
-                                                    _lib.current_stream_ptr()), "bvc_videomae_backward")
+        self._library_backward("bvc_videomae_backward",
+                               _lib.lib().bvc_videomae_backward(self._ctx, g.data_ptr(), target.data_ptr(), cb, None, _lib.current_stream_ptr()))
         self._publish_grads(target, accumulate)
         self._live = None
 

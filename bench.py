@@ -233,6 +233,9 @@ def main():
         step()
 
     def fence():
+        # drain first: the barrier is a collective on the script's process group, and with BVC_COMM=bvc the step's own collectives
+        # run on another communicator - the two never have work in flight together
+        torch.cuda.synchronize()
         if use_ddp:
             dist.barrier()
         torch.cuda.synchronize()
@@ -296,8 +299,9 @@ def main():
         torch.cuda.synchronize()
         rep = xmodel.bucket_report()
         native = bvc.comm.get(dev)
-        comm = {"backend": ("rccl via libbvc_hip.so (bvc_allreduce_bucket): " + native.library) if xmodel.comm_backend == "bvc-rccl"
-                else "rccl via torch.distributed (nccl)",
+        comm = {"backend": ("rccl via libbvc_hip.so (bvc_allreduce_bucket / bvc_allreduce; BVC_COMM=bvc): " + native.library)
+                if xmodel.comm_backend == "bvc-rccl" else "rccl via torch.distributed (nccl), the script's process group (default)",
+                "communicators_in_step": 1,
                 "ranks": dist.get_world_size(), "bucket_cap_mb": args.bucket_mb, "buckets_last_step": rep[-1] if rep else []}
         xmodel.profile_buckets = False
     stream_info = None

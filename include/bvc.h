@@ -322,9 +322,10 @@ const char* bvc_comm_library(void);
 int bvc_allreduce_bucket(bvc_comm* comm, float* buf_dev, int64_t count, int average, void* producer_stream);
 /* `stream` waits (event, no host block) for every bucket enqueued so far: end of backward, before the optimiser reads the gradients */
 int bvc_comm_wait(bvc_comm* comm, void* stream);
-/* Collectives that run ON the caller's stream (their result is consumed next):
+/* Collectives whose result the caller's next kernels consume.  They too run on the communication stream (one communicator, one
+ * stream, program order), fenced both ways: after everything enqueued on `stream` so far, and `stream` continues after them.
  *   allgather  recv[r * bytes_per_rank ...] = rank r's send buffer           (SimCLR global-batch negatives, forward)
- *   allreduce  in-place sum / mean of count f32                              (its backward; the loss scalar)
+ *   allreduce  in-place sum / mean of count f32                              (its backward; the loss scalar of AllReduce, ddputils.py:53-68)
  *   broadcast  root's buffer to every rank                                   (module-state sync at wrap time) */
 int bvc_allgather(bvc_comm* comm, const void* send_dev, void* recv_dev, int64_t bytes_per_rank, void* stream);
 int bvc_allreduce(bvc_comm* comm, float* buf_dev, int64_t count, int average, void* stream);

@@ -252,7 +252,63 @@ def _body_simclr(rank, world, bvc):
     return (_flat_grad_of(model.trunk), loose, state, float(loss))
 
 
-BODIES = {"videomae": _body_videomae, "jepa": _body_jepa, "simclr": _body_simclr}
+class _CallLog:
+    """Records every torch.distributed collective a rank issues, in order: (name, element count)."""
+    names = ("all_reduce", "broadcast", "all_gather_into_tensor")
+
+    def __init__(self):
+        self.calls = []
+        self.saved = {n: getattr(dist, n) for n in self.names}
+        for n in self.names:
+            def wrapped(t, *a, _n=n, _f=self.saved[n], **k):
+                self.calls.append((_n, int(t.numel())))
+                return _f(t, *a, **k)
+            setattr(dist, n, wrapped)
+
+    def restore(self):
+        for n, f in self.saved.items():
+            setattr(dist, n, f)
+
+
+class _SimModelUnused(_SimModel):
+    """The composite with one more ordinary parameter that `forward` uses on even steps only: a backward in which a loose
+    parameter receives no gradient must neither skip the coalesced all-reduce nor shift it into the next step."""
+
+    def __init__(self, bvc, seed):
+        super().__init__(bvc, seed)
+        self.extra = nn.Parameter(torch.full((SIM["p"],), 0.5))
+        self.use_extra = True
+
+    def forward(self, x):
+        y = super().forward(x)
+        return y + self.extra if self.use_extra else y
+
+
+def _body_robust(rank, world, bvc):
+    from oracle import simclr_oracle as so
+    log = _CallLog()
+    try:
+        model = _SimModelUnused(bvc, seed=21 + rank)
+        ddp = bvc.ddp.DistributedDataParallel(model, bucket_cap_mb=1e-4)
+        n = 2 * SIM["per_rank"]
+        masks = so.make_masks(SIM["per_rank"] * world)
+        outs = []
+        for it in range(3):
+            model.use_extra = it != 1                     # step 1: `extra` gets no gradient on any rank
+            for p in model.parameters():
+                p.grad = None
+            x = _sim_batch(n * world, seed=31 + it)[n * rank:n * rank + n]
+            loss = so.info_nce_loss(SIM["T"], masks, bvc.distributed.AllGather.apply(ddp(x)))
+            loss.backward()
+            loss_all = bvc.AllReduce.apply(loss.detach())
+            outs.append((_flat_grad_of(model.trunk), torch.cat([p.grad.reshape(-1) for p in model.fc.parameters()]),
+                         None if model.extra.grad is None else model.extra.grad.clone(), float(loss_all)))
+        return (outs, list(log.calls))
+    finally:
+        log.restore()
+
+
+BODIES = {"videomae": _body_videomae, "jepa": _body_jepa, "simclr": _body_simclr, "robust": _body_robust}
 
 
 def _entry(body, rank, world, port, q):
@@ -381,3 +437,43 @@ def test_simclr_composite_global_batch_nce_matches_single_process():
         assert float((gt - g_trunk).norm() / g_trunk.norm()) < 2e-5, rank      # flat trunk: bucketed all-reduce
         assert float((gl - g_loose).norm() / g_loose.norm()) < 2e-5, rank      # ordinary head parameters: coalesced all-reduce
     assert torch.equal(got[0][0], got[1][0]) and torch.equal(got[0][1], got[1][1])
+
+
+@pytest.mark.timeout(600)
+def test_loose_parameter_without_gradient_and_collective_call_order():
+    """(1) ONE communicator, one order: both ranks issue exactly the same sequence of collectives (name, size) through three
+    steps - module-state broadcasts, the all-gather, trunk buckets, the coalesced head all-reduce, the loss all-reduce.
+    (2) A step in which an ordinary parameter receives no gradient still averages the others (the flush is an end-of-backward
+    callback, not a count of hook firings), with the same collective sizes on every rank and step, and the next step is unaffected."""
+    sys.path.insert(0, ROOT)
+    bvc = _load()
+    from oracle import simclr_oracle as so
+    world = 2
+    got = _run("robust", world)
+    (o0, calls0), (o1, calls1) = got
+    assert calls0 == calls1 and len(calls0) > 10
+    # per step: all_gather fwd, then (trunk buckets | all-gather backward | head) all_reduces, then the loss scalar last
+    per_step = [c for c in calls0 if c[0] != "broadcast"]
+    assert len(per_step) % 3 == 0
+    k = len(per_step) // 3
+    assert per_step[:k] == per_step[k:2 * k] == per_step[2 * k:]           # same collectives, same sizes, every step
+    assert per_step[k - 1] == ("all_reduce", 1)                            # the loss scalar follows the step's gradient exchange
+    # single process, global batch, rank 0's parameters
+    model = _SimModelUnused(bvc, seed=21)
+    n = 2 * SIM["per_rank"] * world
+    for it in range(3):
+        model.use_extra = it != 1
+        for p in model.parameters():
+            p.grad = None
+        loss = so.info_nce_loss(SIM["T"], so.make_masks(SIM["per_rank"] * world), model(_sim_batch(n, seed=31 + it)))
+        loss.backward()
+        g_trunk = _flat_grad_of(model.trunk)
+        g_loose = torch.cat([p.grad.reshape(-1) for p in model.fc.parameters()])
+        for rank, outs in enumerate((o0, o1)):
+            gt, gl, ge, ls = outs[it]
+            assert float((gt - g_trunk).norm() / g_trunk.norm()) < 2e-5, (it, rank)
+            assert float((gl - g_loose).norm() / g_loose.norm()) < 2e-5, (it, rank)
+            assert (ge is None) == (model.extra.grad is None), (it, rank)
+            if ge is not None:
+                assert torch.allclose(ge, model.extra.grad, rtol=1e-4, atol=1e-6), (it, rank)
+            assert abs(ls - float(loss)) < 1e-5 * abs(float(loss))

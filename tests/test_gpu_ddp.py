@@ -19,10 +19,33 @@ bvc = G.bvc
 dev = torch.device("cuda:0")
 
 
-def test_ddp_wrapper_rccl_single_rank():
+class _NoTorchCollectives:
+    """Inside the block every torch.distributed collective raises: with the library's communicator requested (BVC_COMM=bvc) a
+    training step - buckets, loose gradients, loss all-reduce, all-gather - must not touch the script's process group at all."""
+    names = ("all_reduce", "broadcast", "all_gather_into_tensor", "all_gather", "reduce_scatter_tensor", "barrier")
+
+    def __enter__(self):
+        self.saved = {n: getattr(dist, n) for n in self.names}
+        for n in self.names:
+            def boom(*a, _n=n, **k):
+                raise AssertionError(f"torch.distributed.{_n} called inside a step although BVC_COMM=bvc")
+            setattr(dist, n, boom)
+        return self
+
+    def __exit__(self, *exc):
+        for n, f in self.saved.items():
+            setattr(dist, n, f)
+        return False
+
+
+@pytest.mark.parametrize("which", ["torch", "bvc"])
+def test_ddp_wrapper_rccl_single_rank(which, monkeypatch):
+    import contextlib
+    monkeypatch.setenv("BVC_COMM", which)
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29533")
+    os.environ["MASTER_PORT"] = "29533" if which == "torch" else "29532"
     dist.init_process_group("nccl", rank=0, world_size=1)
+    guard = _NoTorchCollectives if which == "bvc" else contextlib.nullcontext
     try:
         cfg = vo.TINY
         params = vo.make_params(cfg, seed=3)
@@ -47,6 +70,7 @@ def test_ddp_wrapper_rccl_single_rank():
         opt = torch.optim.SGD(ddp.parameters(), lr=0.1, momentum=0.9, nesterov=True)
         scaler = torch.amp.GradScaler("cuda")
         for _ in range(2):
+          with guard():
             opt.zero_grad()
             with torch.autocast("cuda", dtype=torch.bfloat16):
                 o = ddp(px, bool_masked_pos=mk)
@@ -57,7 +81,8 @@ def test_ddp_wrapper_rccl_single_rank():
                 g = model.flat_grads() / scaler.get_scale()
                 assert abs(float(loss) - ref_loss) / ref_loss < 1e-6
                 assert G.rel_err(g, ref_grad) < 1e-5
-                assert ddp.comm_backend == "bvc-rccl"      # the buckets went through bvc_allreduce_bucket, not torch.distributed
+                # ONE communicator per step: the library's (bvc_allreduce_bucket / bvc_allreduce) or the script's process group
+                assert ddp.comm_backend == ("bvc-rccl" if which == "bvc" else "torch-nccl")
                 # several buckets were reduced on the comm stream and together they tile the whole buffer
                 covered = sorted(ddp.reduced_ranges)
                 assert len(covered) >= 2 and covered[0][0] == 0 and covered[-1][1] == ref_grad.numel()
@@ -83,12 +108,16 @@ def _rccl_group(port):
     dist.init_process_group("nccl", rank=0, world_size=1)
 
 
-def test_ddp_jepa_three_wraps_rccl_single_rank():
-    """pretrain_jepa.py:302-304 with bvc's class: encoder, predictor and target encoder wrapped separately.  With one rank the
+@pytest.mark.parametrize("which,device_ids", [("bvc", [0]), ("bvc", None), ("torch", None)])
+def test_ddp_jepa_three_wraps_rccl_single_rank(which, device_ids, monkeypatch):
+    """pretrain_jepa.py:302-304 with bvc's class: encoder, predictor and target encoder wrapped separately - also in the
+    reference's own call form, DDP(encoder, static_graph=True) with NO device_ids, where the wrapper must find the device itself
+    and set everything up (flat buffers, communicator) in its constructor, not inside the first backward.  With one rank the
     collectives are identities, so gradients must equal the unwrapped modules'; the predictor reports its gradient ranges
     per block (bvc_predictor_backward_cb), the encoder per layer, and every byte of both buffers is reduced exactly once."""
     import copy
     from oracle import jepa_oracle as jo
+    monkeypatch.setenv("BVC_COMM", which)
     _rccl_group(29534)
     try:
         cfg = jo.TINY
@@ -124,9 +153,14 @@ def test_ddp_jepa_three_wraps_rccl_single_rank():
         ref_loss = step(enc0, pred0, tgt0)
         enc, pred, tgt = build()
         DDP = bvc.DistributedDataParallel
-        wenc = DDP(enc, device_ids=[0], static_graph=True, bucket_cap_mb=0.05, force_collectives=True)
-        wpred = DDP(pred, device_ids=[0], static_graph=True, bucket_cap_mb=0.05, force_collectives=True)
-        wtgt = DDP(tgt, device_ids=[0], force_collectives=True)
+        ids = dict(device_ids=device_ids) if device_ids else {}
+        wenc = DDP(enc, static_graph=True, bucket_cap_mb=0.05, force_collectives=True, **ids)
+        wpred = DDP(pred, static_graph=True, bucket_cap_mb=0.05, force_collectives=True, **ids)
+        wtgt = DDP(tgt, force_collectives=True, **ids)
+        for w in (wenc, wpred, wtgt):
+            assert w._device == dev                       # found without device_ids
+            assert w.comm_backend == ("bvc-rccl" if which == "bvc" else "torch-nccl")     # decided in the constructor
+        assert enc._flat is not None and pred._flat is not None
         loss = step(wenc, wpred, wtgt)
         assert abs(loss - ref_loss) / ref_loss < 1e-6
         assert G.rel_err(enc.flat_grads(), enc0.flat_grads()) < 1e-6 and G.rel_err(pred.flat_grads(), pred0.flat_grads()) < 1e-6
@@ -141,10 +175,12 @@ def test_ddp_jepa_three_wraps_rccl_single_rank():
         dist.destroy_process_group()
 
 
-def test_ddp_composite_simclr_vit_rccl_single_rank():
+@pytest.mark.parametrize("which", ["torch", "bvc"])
+def test_ddp_composite_simclr_vit_rccl_single_rank(which, monkeypatch):
     """pretrain_simclr.py:227-228 for the config-5 model: SimCLRViT = flat ViT trunk + ordinary-parameter head under ONE wrapper
     (trunk gradients through the bucket hooks, head gradients through the coalesced all-reduce), global InfoNCE behind
     AllGather.  One rank: must reproduce the unwrapped model bit for bit in the loss and to round-off in the gradients."""
+    monkeypatch.setenv("BVC_COMM", which)
     _rccl_group(29535)
     try:
         torch.manual_seed(0)
@@ -171,9 +207,11 @@ def test_ddp_composite_simclr_vit_rccl_single_rank():
         ddp = bvc.DistributedDataParallel(model, device_ids=[0], output_device=0, find_unused_parameters=False, bucket_cap_mb=0.05,
                                           force_collectives=True)
         assert len(ddp._flats) == 1 and len(ddp._loose_grad) == 4          # trunk + fc.0.weight / bias, fc.2.weight / bias
-        l1 = bvc.simclr.global_info_nce_loss(0.1, masks, ddp(imgs))
-        l1.backward()
-        torch.cuda.synchronize()
+        import contextlib
+        with (_NoTorchCollectives() if which == "bvc" else contextlib.nullcontext()):
+            l1 = bvc.simclr.global_info_nce_loss(0.1, masks, ddp(imgs))
+            l1.backward()
+            torch.cuda.synchronize()
         assert float(l1) == float(l0)
         assert G.rel_err(model.trunk.flat_grads(), ref.trunk.flat_grads()) < 1e-6
         for (k, p), (_k, q) in zip(model.fc.named_parameters(), ref.fc.named_parameters()):
@@ -185,9 +223,10 @@ def test_ddp_composite_simclr_vit_rccl_single_rank():
         dist.destroy_process_group()
 
 
-def test_library_communicator_single_rank():
+def test_library_communicator_single_rank(monkeypatch):
     """include/bvc.h "communication" through the Python shim: rendezvous over the process group, bucket all-reduce on the
-    library's stream with its fences, collectives on the caller's stream, and the torch.distributed A/B switch."""
+    library's stream with its fences, the result-consumed-next collectives hopping to that stream and back."""
+    monkeypatch.setenv("BVC_COMM", "bvc")
     _rccl_group(29537)
     try:
         c = bvc.comm.get(dev)
@@ -220,8 +259,13 @@ def test_library_communicator_single_rank():
         dist.destroy_process_group()
 
 
-def test_torch_distributed_fallback_switch(monkeypatch):
-    monkeypatch.setenv("BVC_COMM", "torch")
+@pytest.mark.parametrize("value", [None, "torch"])
+def test_torch_distributed_is_the_default(monkeypatch, value):
+    """The library communicator is opt-in (BVC_COMM=bvc) until a multi-rank run on GPUs has been recorded."""
+    if value is None:
+        monkeypatch.delenv("BVC_COMM", raising=False)
+    else:
+        monkeypatch.setenv("BVC_COMM", value)
     _rccl_group(29538)
     try:
         assert bvc.comm.get(dev) is None

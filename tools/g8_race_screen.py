@@ -80,6 +80,11 @@ for layout, epi, M, N, K, tile in cases:
             ok = ok and abs(float(got[2].sum()) - float(ref[2].sum())) <= 1e-4 * abs(float(ref[2].sum()))
         if layout == G.TN:     # the fused bias gradient is atomically accumulated over column-0 workgroups only: order-free sums
             ok = ok and float((got[3] - ref[3]).norm()) <= 2e-5 * float(ref[3].norm())
+        if not ok and mism == 0:      # say what differs, once per case
+            d = (got[0].float() - ref[0].float()).abs()
+            print(f"   first mismatch at launch {it}: C max abs diff {float(d.max()):.3e} in {int((d > 0).sum())} elements"
+                  f" (|C| max {float(ref[0].float().abs().max()):.3e}); partial sums {float(got[2].sum()):.9e} vs {float(ref[2].sum()):.9e};"
+                  f" rowsum diff {float((got[3] - ref[3]).norm()):.3e}", flush=True)
         mism += 0 if ok else 1
     torch.cuda.synchronize()
     print(f"{['NT', 'NN', 'TN'][layout]} {epi:5s} M={M} N={N} K={K} tile{tile}: {iters} launches, {mism} mismatches", flush=True)

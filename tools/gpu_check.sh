@@ -49,6 +49,7 @@ print("\n".join(rows))
 PY
               ;;
     ops)   run ops 420 python -m pytest tests/test_gpu_ops.py -m gpu -q -p no:cacheprovider ;;
+    ddp)   run ddptests 420 python -m pytest tests/test_gpu_ddp.py -m gpu -q -x -p no:cacheprovider ;;
     model) run model 420 python -m pytest tests/test_gpu_videomae.py -m gpu -q -p no:cacheprovider ;;
     all)   run alltests 900 python -m pytest tests -m gpu -q -x -p no:cacheprovider ;;
     smoke) run smoke 200 python -c "import __graft_entry__ as g; g.smoke()" ;;

@@ -442,6 +442,7 @@ __global__ __launch_bounds__(256, LB) void gemm_kernel(const GemmGroup g) {
 // ------------------------------------------------------------------ host side
 static void tile_dims(int cfg, int& bm, int& bn) {
     if (cfg == 10 || cfg == 11) { bm = 256; bn = cfg == 10 ? 256 : 128; return; }    // gemm8.hip
+    if (cfg == 12) { bm = 128; bn = 384; return; }                                     // gemm8.hip, weight gradients of 384-multiples
     bm = cfg == 2 ? 64 : 128;
     bn = cfg == 0 ? 128 : 64;
 }
@@ -455,7 +456,7 @@ static int tiles_for(const GemmProblem& p, int cfg) {
 int gemm_pick_tile(const GemmProblem* probs, int nprob, int tile_cfg) {
     if (tile_cfg == 6 || tile_cfg == 7) return tile_cfg - 6;     // the persistent kernel: 128x128 / 128x64 tiles
     if (tile_cfg == 9) return 0;                                  // persistent 128x128 with deferred stores
-    if (tile_cfg == 10 || tile_cfg == 11) return tile_cfg;        // gemm8.hip: 256x256 / 256x128
+    if (tile_cfg >= 10 && tile_cfg <= 12) return tile_cfg;        // gemm8.hip: 256x256 / 256x128 / 128x384
     if (tile_cfg >= 0) return tile_cfg;
     // Measured on MI355X (profiles/r01_b_microbench.json): a workgroup's speed is set by its L2->LDS fill
     // rate (~70 GB/s per CU), so the big tile (64 FLOP/B) wins once it alone covers the 256 CUs ~1.5x;
@@ -636,7 +637,7 @@ int launch_gemm(const GemmProblem* probs, int nprob, GemmLayout layout, int tile
                         "launch_gemm: split_k needs an accumulating f32 epilogue");
         g.prob[i] = p;
         g.panel[i] = pick_panel(p, cfg, layout);
-        if ((cfg == 10 || cfg == 11) && layout == GEMM_TN && BVC_EXP_ENV("BVC_G8_TN_LEGACY_WALK") == nullptr) {
+        if (cfg >= 10 && cfg <= 12 && layout == GEMM_TN && BVC_EXP_ENV("BVC_G8_TN_LEGACY_WALK") == nullptr) {
             // weight gradients on the persistent kernel: K splits SLOWEST, tiles row-major inside a split.  An XCD's ~32 resident
             // units are then the tiles of one or two K ranges of one problem, which share their dY / X slices through its L2; with
             // the splits fastest (the 128 x 128 kernel's walk) neighbours share nothing and every unit streams its own slices
@@ -650,15 +651,15 @@ int launch_gemm(const GemmProblem* probs, int nprob, GemmLayout layout, int tile
     }
     g.tile_start[nprob] = total;
     for (int i = nprob; i < kMaxGroup; ++i) { g.prob[i] = probs[0]; g.panel[i] = g.panel[0]; g.tile_start[i + 1] = total; }
-    if (cfg == 10 || cfg == 11) {
-        const int rc = launch_gemm8(g, layout, cfg == 10 ? 256 : 128, stream);
+    if (cfg >= 10 && cfg <= 12) {
+        const int rc = launch_gemm8(g, layout, cfg == 10 ? 256 : cfg == 11 ? 128 : 384, stream);
         if (rc == 1 && auto_g8) {     // the selection and the kernel's own eligibility test disagree: never an error for the caller
             skip_g8 = true;
             const int rc2 = launch_gemm(probs, nprob, layout, -1, stream, stages);
             skip_g8 = false;
             return rc2;
         }
-        BVC_REQUIRE(rc != 1, "launch_gemm: tile configs 10 / 11 (256-row persistent kernel) do not take this problem");
+        BVC_REQUIRE(rc != 1, "launch_gemm: tile configs 10 - 12 (persistent one-workgroup-per-CU kernel) do not take this problem");
         return rc;
     }
     int kmax = 0;

@@ -23,6 +23,12 @@
 // group (q + 2) & 3; the stream of groups never skips: past the last unit the loads are issued with an out-of-range offset
 // (the buffer descriptor drops them, the counter still counts them), which keeps every counted wait exact.
 // Results are bit-identical to gemm_kernel's for the same problem (same K order per output element, same epilogue math).
+//
+// Round 3: a third geometry for weight gradients, 128 x 384 tiles (BM = 128, BN = 384; tile config 12).  Every width of the
+// decoder and of the JEPA predictor is a multiple of 384 (384, 1152, 1536): on 256-wide tiles the four weight gradients of a
+// decoder layer fill 71 % of the MFMA work they execute (38 tiles of 65536 outputs for 1.77 M outputs), on 128 x 384 tiles 100 %
+// (36 tiles of 49152).  Same stream, same phases: wave tile 64 x 96 (4 x 6 MFMA tiles, 12 MFMAs per phase), one A half and three
+// B halves per K tile (again 128 KiB of staging), groups of 3 + 1 + 3 + 1 LDS-DMA pieces.
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -57,7 +63,7 @@ __device__ __forceinline__ bf16x8 tr_frag(uint32_t region, uint32_t lane_base, u
 }
 
 // unit id -> problem, tile, K range.  Uniform (kernel arguments and blockIdx only).
-template <int BN>
+template <int BM, int BN>
 __device__ __forceinline__ void decode_unit(const GemmGroup& g, int uid, Unit& u) {
     int pi = 0;
 #pragma unroll
@@ -65,7 +71,7 @@ __device__ __forceinline__ void decode_unit(const GemmGroup& g, int uid, Unit& u
         if (i < g.nprob && uid >= g.tile_start[i]) pi = i;
     const GemmProblem& p = g.prob[pi];
     const int lid = uid - g.tile_start[pi];
-    const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + 255) / 256;
+    const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
     const int ntiles = tiles_m * tiles_n;
     const int G = g.panel[pi];
     int split, tm, tn;
@@ -84,7 +90,7 @@ __device__ __forceinline__ void decode_unit(const GemmGroup& g, int uid, Unit& u
     per = (per + 1) & ~1;                        // the K loop is unrolled over two K tiles (LDS slot parity)
     // integer divisions run on the vector ALU: pin the (uniform) results to scalar registers
     u.pi = pi;
-    u.m0 = __builtin_amdgcn_readfirstlane(tm * 256);
+    u.m0 = __builtin_amdgcn_readfirstlane(tm * BM);
     u.n0 = __builtin_amdgcn_readfirstlane(tn * BN);
     u.kt0 = __builtin_amdgcn_readfirstlane(split * per);
     u.nkt = __builtin_amdgcn_readfirstlane(per);
@@ -97,13 +103,17 @@ __device__ __forceinline__ void decode_unit(const GemmGroup& g, int uid, Unit& u
 // EC (epilogue class): 0 = bf16 outputs without side inputs (BF16, GELU, RELU); 3 = bf16 outputs gated by a bf16 side input (DGELU,
 // DRELU); 1 = f32 side inputs / outputs (F32, RESID, POS, E2D, LOSS, F32_BF16); 2 = weight gradients (TN): f32 store or split-K
 // atomics, fused bias gradient.  Classes are separate instantiations because the side inputs of a whole unit sit in registers.
-template <int BN, bool AT, bool BT, int EC>
+template <int BM, int BN, bool AT, bool BT, int EC>
 __global__ __launch_bounds__(512, 1) void gemm8_kernel(const GemmGroup g, const int total_units) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int A_BYTES = 256 * 64 * 2, B_BYTES = BN * 64 * 2, TILE = A_BYTES + B_BYTES;
-    constexpr int WN = BN / 4, TN = WN / 16, TM = 8;
-    constexpr int NB = BN / 64, NBH = BN / 128;
-    constexpr int n0c = AT ? NBH : (NB < 2 ? NB : 2), n1c = AT ? 2 : NB - n0c, n2c = AT ? NBH : 2, n3c = 2;
+    static_assert(BM == 256 || (BM == 128 && BN == 384 && AT && BT && EC == 2), "128-row tiles: the 128 x 384 weight-gradient geometry only");
+    static_assert(BN == 256 || BN == 128 || (BN == 384 && BM == 128), "column tiles of 256 / 128, or 384 with 128 rows");
+    constexpr int A_BYTES = BM * 64 * 2, B_BYTES = BN * 64 * 2, TILE = A_BYTES + B_BYTES;
+    constexpr int WMR = BM / 2;                          // rows of a wave row
+    constexpr int WN = BN / 4, TN = WN / 16, TM = WMR / 16, TMH = TM / 2;
+    constexpr int NB = BN / 64, NBH = BN / 128, NAH = BM / 128;
+    constexpr int n0c = AT ? NBH : (NB < 2 ? NB : 2), n1c = AT ? NAH : NB - n0c, n2c = AT ? NBH : 2, n3c = AT ? NAH : 2;
+    constexpr int KMAX = (n0c > 2 || n1c > 2 || n2c > 2 || n3c > 2) ? 3 : 2;      // most LDS-DMA pieces in one group
     constexpr int PT = n0c + n1c + n2c + n3c;          // LDS-DMA instructions per wave per K tile
     // Where a phase issues its group.  EARLY (default): in the read segment, after the fragment reads and before the counted wait -
     // the wave stalls on the LDS-DMA issue (100-185 cycles per instruction there) while the OTHER wave row of its SIMD issues
@@ -116,7 +126,7 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const GemmGroup g, const 
 #else
     constexpr bool LATE = false;
 #endif
-    constexpr int CPR = WN / 8;                   // epilogue geometry: 8-column chunks per wave-tile row
+    constexpr int CPR = BN == 384 ? 8 : WN / 8;   // epilogue geometry: 8-column chunks per wave-tile row (unused by the 384-wide tile)
     constexpr int NSIDE = TM * (16 / (64 / CPR));  // 16-byte chunks (= bf16 store instructions per output) per lane and unit
     static_assert(PT + 2 * NSIDE < 64, "vmcnt is a 6-bit counter");
     constexpr int WP = AT ? PT : n3c + n0c + n1c;                                        // prologue: K tile 0's phase-0 operands
@@ -137,7 +147,7 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const GemmGroup g, const 
 
     // ------------------------------------------------------------------ the staging cursor (runs ahead of the compute)
     Unit su;
-    decode_unit<BN>(g, uid, su);
+    decode_unit<BM, BN>(g, uid, su);
     int s_uid = uid, s_kt = 0;
     bool s_valid = true;
     __amdgpu_buffer_rsrc_t s_ra, s_rb;
@@ -179,7 +189,7 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const GemmGroup g, const 
             s_uid += nslots;
             if (s_uid < x_hi) {
                 const int old = su.pi;
-                decode_unit<BN>(g, s_uid, su);
+                decode_unit<BM, BN>(g, s_uid, su);
                 if (su.pi != old) s_problem();
             } else {
                 s_valid = false;
@@ -194,8 +204,13 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const GemmGroup g, const 
     // lane constants of the transposed fragment reads (tr_frag)
     const uint32_t tr_base = (uint32_t)((8 * (lane >> 4) + ((lane >> 2) & 3)) * 256 + ((lane & 3) >> 1) * 16 + (lane & 1) * 8);
     const uint32_t tr_swz = (uint32_t)swz_tr<128>(8 * (lane >> 4) + ((lane >> 2) & 3)) << 4;
-    const uint32_t b_region = (uint32_t)(A_BYTES + ((wn * WN) >> 7) * 16384);      // this wave's half of a transposed B tile
-    const uint32_t b_chunk16 = (uint32_t)(2 * ((wn * WN) & 127));                  // its first column, in address bits
+    // fragment j of this wave's transposed B columns (wn WN + 16 j): which 128-column half, and the column in address bits.  A 64- or
+    // 32-wide wave tile sits inside one half; the 96-wide one of the 384-column tile straddles (uniform arithmetic, scalar registers)
+    auto b_region = [&](int j) -> uint32_t { return (uint32_t)(A_BYTES + ((wn * WN + 16 * j) >> 7) * 16384); };
+    auto b_chunk16 = [&](int j) -> uint32_t { return (uint32_t)(2 * ((wn * WN + 16 * j) & 127)); };
+    // this wave row's A rows in a transposed A tile: half wm of a 256-row tile, rows 64 wm .. of the single half of a 128-row one
+    const uint32_t a_region = BM == 256 ? (uint32_t)wm * 16384u : 0u;
+    const uint32_t a_chunk0 = BM == 256 ? 0u : (uint32_t)wm * 128u;
     auto load_a = [&](char* region, int j) {
         const uint32_t off = s_la + s_baseA + (AT ? (uint32_t)(j & 1) * s_strideA + (uint32_t)(j >> 1) * 256u : (uint32_t)j * s_strideA);
         glds16(s_ra, off, lds0 + (uint32_t)(region - smem) + (uint32_t)j * 8192u);
@@ -216,18 +231,21 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const GemmGroup g, const 
         char* rb_ = buf + A_BYTES;
         if constexpr (!AT) {
             if constexpr (GI == 0) { if constexpr (K < n0c) load_b(rb_, K); }
-            else if constexpr (GI == 1) { if constexpr (n0c + K < NB) load_b(rb_, n0c + K); }
-            else if constexpr (GI == 2) load_a(ra_, K == 0 ? 0 : 2);
-            else load_a(ra_, K == 0 ? 1 : 3);
-        } else {
+            else if constexpr (GI == 1) { if constexpr (K < n1c) load_b(rb_, n0c + K); }
+            else if constexpr (GI == 2) { if constexpr (K < 2) load_a(ra_, K == 0 ? 0 : 2); }
+            else { if constexpr (K < 2) load_a(ra_, K == 0 ? 1 : 3); }
+        } else {       // k rows 0-31 of every B half, of every A half, then k rows 32-63 likewise (piece 2 h + (k >= 32) of half h)
             if constexpr (GI == 0) { if constexpr (K < NBH) load_b(rb_, 2 * K); }
-            else if constexpr (GI == 1) load_a(ra_, K == 0 ? 0 : 2);
+            else if constexpr (GI == 1) { if constexpr (K < NAH) load_a(ra_, 2 * K); }
             else if constexpr (GI == 2) { if constexpr (K < NBH) load_b(rb_, 2 * K + 1); }
-            else load_a(ra_, K == 0 ? 1 : 3);
+            else { if constexpr (K < NAH) load_a(ra_, 2 * K + 1); }
         }
-        if constexpr (GI == 3 && K == 1) s_advance();
+        if constexpr (GI == 3 && K == KMAX - 1) s_advance();
     };
-    auto stage_group = [&](auto gi_, char* buf) { stage_one(gi_, I0{}, buf); stage_one(gi_, I1{}, buf); };
+    auto stage_group = [&](auto gi_, char* buf) {
+        stage_one(gi_, I0{}, buf); stage_one(gi_, I1{}, buf);
+        if constexpr (KMAX == 3) stage_one(gi_, I2{}, buf);
+    };
     // the group phase q issues: (q + 2) & 3 of the cursor's K tile, into the other slot for q = 0, 1 and into this one for q = 2, 3
     auto stage_phase = [&](auto q_, auto k_, char* cur, char* oth) {
         constexpr int Q = decltype(q_)::value;
@@ -239,7 +257,10 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const GemmGroup g, const 
 
     char* const buf0 = smem;
     char* const buf1 = smem + TILE;
-    AS3 char* const wl = (AS3 char*)smem + 2 * TILE + wave * (16 * WN * 4);   // wave-private epilogue parking: 16 rows x WN f32
+    // wave-private epilogue parking: 16 rows x WN f32 (the 384-wide tile parks 16 rows x 48 columns at a time: 24 KiB for the
+    // eight waves next to 128 KiB of staging)
+    constexpr int PARK = BN == 384 ? 16 * 48 * 4 : 16 * WN * 4;
+    AS3 char* const wl = (AS3 char*)smem + 2 * TILE + wave * PARK;
 
     if constexpr (EC == 0) {
         // the bias vector of the (single) problem, zero padded to whole tiles, into the LDS the other classes park accumulators
@@ -260,7 +281,7 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const GemmGroup g, const 
     if (wm == 1) asm volatile("s_barrier" ::: "memory");     // the stagger: wave row 1 runs one barrier behind wave row 0
 
     Unit cu;
-    decode_unit<BN>(g, uid, cu);
+    decode_unit<BM, BN>(g, uid, cu);
     // First K tile after an epilogue: what its phase-1 wait has to allow for.  0: the stream ran on, the plain counted wait;
     // -1: the epilogue drained every load before its stores, no wait needed; n > 0: the epilogue issued n stores BEHIND the
     // prefetched loads without draining them (vmcnt is one in-order counter), so the wait counts them as younger operations.
@@ -294,14 +315,14 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const GemmGroup g, const 
                         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
                             for (int j = 0; j < TN; ++j)
-                                bfr[ks][j] = BT ? tr_frag(lds_base + (uint32_t)(cur - smem) + b_region, tr_base, sw, b_chunk16 + 32u * j, ks)
+                                bfr[ks][j] = BT ? tr_frag(lds_base + (uint32_t)(cur - smem) + b_region(j), tr_base, sw, b_chunk16(j), ks)
                                                 : read_frag<BN, false>(lb, wn * WN + 16 * j, ks, lane);
                     }
                     bf16x8 af[2][2];
 #pragma unroll
                     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-                        for (int ii = 0; ii < 2; ++ii) af[ks][ii] = read_frag<256, false>(la, wm * 128 + 16 * (2 * q + ii), ks, lane);
+                        for (int ii = 0; ii < 2; ++ii) af[ks][ii] = read_frag<256, false>(la, wm * WMR + 16 * (2 * q + ii), ks, lane);
                     if constexpr (!LATE) { stage_phase(q_, I0{}, cur, oth); stage_phase(q_, I1{}, cur, oth); }
                     if constexpr (q == 1) {
                         if (after_epi == 0) wait_vmcnt<W1>();
@@ -333,17 +354,20 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const GemmGroup g, const 
                     constexpr int q = decltype(q_)::value;
                     constexpr int ks = q >> 1, mh = q & 1;
                     __builtin_amdgcn_sched_barrier(0);
-                    bf16x8 af[4];
+                    bf16x8 af[TMH];
                     uint32_t sw = tr_swz;
                     asm volatile("" : "+v"(sw));
                     const uint32_t slot = lds_base + (uint32_t)(cur - smem);
                     if constexpr (mh == 0) {
 #pragma unroll
-                        for (int j = 0; j < TN; ++j) bfr[j] = tr_frag(slot + b_region, tr_base, sw, b_chunk16 + 32u * j, ks);
+                        for (int j = 0; j < TN; ++j) bfr[j] = tr_frag(slot + b_region(j), tr_base, sw, b_chunk16(j), ks);
                     }
 #pragma unroll
-                    for (int ii = 0; ii < 4; ++ii) af[ii] = tr_frag(slot + (uint32_t)wm * 16384u, tr_base, sw, 32u * (4 * mh + ii), ks);
-                    if constexpr (!LATE) { stage_phase(q_, I0{}, cur, oth); stage_phase(q_, I1{}, cur, oth); }
+                    for (int ii = 0; ii < TMH; ++ii) af[ii] = tr_frag(slot + a_region, tr_base, sw, a_chunk0 + 32u * (TMH * mh + ii), ks);
+                    if constexpr (!LATE) {
+                        stage_phase(q_, I0{}, cur, oth); stage_phase(q_, I1{}, cur, oth);
+                        if constexpr (KMAX == 3) stage_phase(q_, I2{}, cur, oth);
+                    }
                     if constexpr (q == 1) {
                         if (after_epi == 0) wait_vmcnt<W1>();
                         else if (after_epi == NSIDE) wait_vmcnt<W1 + NSIDE>();
@@ -353,27 +377,31 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const GemmGroup g, const 
                     asm volatile("s_barrier" ::: "memory");   // fragment reads are builtins: hipcc places counted lgkmcnt waits in front of the MFMAs that use them
                     __builtin_amdgcn_sched_barrier(0);
                     __builtin_amdgcn_s_setprio(1);
-                    constexpr int NM = 4 * TN;
+                    constexpr int NM = TMH * TN;
 #pragma unroll
                     for (int t = 0; t < NM; ++t) {
                         const int ii = t / TN, j = t % TN;
-                        acc[4 * mh + ii][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[ii], acc[4 * mh + ii][j], 0, 0, 0);
+                        acc[TMH * mh + ii][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[ii], acc[TMH * mh + ii][j], 0, 0, 0);
                         if constexpr (LATE) {
                             if (t == NM / 4 - 1) stage_phase(q_, I0{}, cur, oth);
                             if (t == NM / 2 - 1) stage_phase(q_, I1{}, cur, oth);
                         }
                     }
-                    if (RS && do_rowsum) {
-                        // bias gradient db[m] = sum_k A(m, k): wave column wn sums the fragment of row tile 4 mh + wn it has in
+                    if (RS && do_rowsum && wn < TMH) {
+                        // bias gradient db[m] = sum_k A(m, k): wave column wn sums the fragment of row tile TMH mh + wn it has in
                         // registers anyway (16 vector instructions per phase, no extra MFMA, no extra accumulator tile: the
                         // all-ones-operand MFMA this replaces cost ~45 live registers and made the 256 x 256 instantiation
                         // spill).  Lane l holds 8 k values of row l & 15; the k groups are folded by two shuffles at the end.
                         bf16x8 a;
-                        switch (wn) {
-                            case 0: a = af[0]; break;
-                            case 1: a = af[1]; break;
-                            case 2: a = af[2]; break;
-                            default: a = af[3]; break;
+                        if constexpr (TMH == 4) {
+                            switch (wn) {
+                                case 0: a = af[0]; break;
+                                case 1: a = af[1]; break;
+                                case 2: a = af[2]; break;
+                                default: a = af[3]; break;
+                            }
+                        } else {
+                            a = wn == 0 ? af[0] : af[1];
                         }
                         union { bf16x8 v; uint32_t u[4]; } w;
                         w.v = a;
@@ -446,7 +474,7 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const GemmGroup g, const 
             const int ncol = n0 + wn * WN + 16 * (q4 & 1) + 8 * (q4 >> 1);
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                const int m = m0 + wm * 128 + 16 * i + (lane & 15);
+                const int m = m0 + wm * WMR + 16 * i + (lane & 15);
 #pragma unroll
                 for (int jp = 0; jp < TN / 2; ++jp) {
                     float va[4], vb[4];
@@ -480,6 +508,32 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const GemmGroup g, const 
                 }
             }
             nstores = two_out ? 2 * NSIDE : NSIDE;
+        } else if constexpr (BN == 384) {
+            // 128 x 384 weight-gradient tile: the wave's 64 x 96 outputs leave through 16 rows x 48 columns of parking at a time (two
+            // passes per row tile), one dword per lane - runs of 64 consecutive floats of the row-major [16][48] image, i.e. 64-byte
+            // aligned pieces of one or two output rows per wave-instruction; f32 atomics when K is split (the memory-side atomic units
+            // take a wave-instruction as four 64-byte requests whatever the rows), plain stores otherwise.  Once per ~900 K tiles.
+            const __amdgpu_buffer_rsrc_t rca = make_rsrc(p.C, kDrop);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int ps = 0; ps < 2; ++ps) {
+                    const int prow = lane & 15;
+#pragma unroll
+                    for (int jj = 0; jj < 3; ++jj)
+                        *reinterpret_cast<AS3 f32x4*>(wl + prow * 192 + (4 * jj + (lane >> 4)) * 16) = acc[i][3 * ps + jj];
+#pragma unroll
+                    for (int t = 0; t < 16 * 48 / 64; ++t) {
+                        const int idx = t * 64 + lane;
+                        const int row = idx / 48, col = idx % 48;
+                        const int m = m0 + wm * WMR + 16 * i + row, n = n0 + wn * WN + 48 * ps + col;
+                        const float v = *reinterpret_cast<const AS3 float*>(wl + row * 192 + col * 4) * alpha;
+                        const uint32_t o = (m < Mrows && n < Ncols) ? (uint32_t)(((size_t)m * ldc + n) * 4) : kDrop;
+                        if (atomic) __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(v, rca, o, 0, 0);
+                        else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rca, o, 0, 0);
+                    }
+                }
+            }
         } else if (EC == 2 && atomic) {
             // split-K: f32 atomics, one dword per lane, whole contiguous rows per wave-instruction (256 B / two 128-B rows: the shape
             // the memory-side atomic units take at full rate), through a buffer descriptor (32-bit offsets, dropped when out of range)
@@ -491,7 +545,7 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const GemmGroup g, const 
                 for (int t = 0; t < 16 * WN / 64; ++t) {
                     const int idx = t * 64 + lane;
                     const int row = idx / WN, col = idx % WN;
-                    const int m = m0 + wm * 128 + 16 * i + row, n = n0 + wn * WN + col;
+                    const int m = m0 + wm * WMR + 16 * i + row, n = n0 + wn * WN + col;
                     const int unit = (col >> 2) ^ (row & (UNITS - 1));
                     const float v = *reinterpret_cast<const AS3 float*>(wl + row * (WN * 4) + unit * 16 + (col & 3) * 4) * alpha;
                     const uint32_t o = (m < Mrows && n < Ncols) ? (uint32_t)(((size_t)m * ldc + n) * 4) : kDrop;
@@ -531,7 +585,7 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const GemmGroup g, const 
                 const int ldaux = p.ldaux;
 #pragma unroll
                 for (int c = 0; c < NSP; ++c) {
-                    const int m = m0 + wm * 128 + 16 * ((c + pass * NSP) / U) + ((((c + pass * NSP) % U) * 64 + lane) / CPR);
+                    const int m = m0 + wm * WMR + 16 * ((c + pass * NSP) / U) + ((((c + pass * NSP) % U) * 64 + lane) / CPR);
                     side0[c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(raux, offs(m, ldaux, 2), 0, 0));
                 }
             } else if constexpr (EC == 1) {
@@ -542,7 +596,7 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const GemmGroup g, const 
                 const __amdgpu_buffer_rsrc_t rtok = make_rsrc(p.rowtok, by_tok ? kDrop : 0u);
 #pragma unroll
                 for (int c = 0; c < NSP; ++c) {
-                    const int m = m0 + wm * 128 + 16 * ((c + pass * NSP) / U) + ((((c + pass * NSP) % U) * 64 + lane) / CPR);
+                    const int m = m0 + wm * WMR + 16 * ((c + pass * NSP) / U) + ((((c + pass * NSP) % U) * 64 + lane) / CPR);
                     uint32_t o = offs(m, ldc, 4);
                     if (by_tok) {
                         const int tok = __builtin_amdgcn_raw_buffer_load_b32(rtok, m < Mrows ? (uint32_t)m * 4u : kDrop, 0, 0);
@@ -570,7 +624,7 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const GemmGroup g, const 
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     const int row = (u * 64 + lane) / CPR;
-                    const int m = m0 + wm * 128 + 16 * i + row;
+                    const int m = m0 + wm * WMR + 16 * i + row;
                     const f32x4 lo = *reinterpret_cast<const AS3 f32x4*>(wl + row * (WN * 4) + (((2 * cc) ^ (row & (UNITS - 1))) << 4));
                     const f32x4 hi = *reinterpret_cast<const AS3 f32x4*>(wl + row * (WN * 4) + (((2 * cc + 1) ^ (row & (UNITS - 1))) << 4));
                     const int c = U * i + u - pass * NSP;
@@ -639,14 +693,17 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const GemmGroup g, const 
                 // parking rows, one lane folds the eight in a fixed order.  The wave rows run one barrier apart, so the fold
                 // sits behind TWO barriers: after the second one wave row 1 has passed the first, i.e. has written.
                 const float w = wave_sum(sumsq);
+                // (a wave's parking area is 16 rows x WN floats: wave q's first word is float 16 WN q.  Round 2 indexed it 4 WN q - inside
+                //  the rows OTHER waves were still reading back: one output element per affected tile came out as a partial sum; found by
+                //  tools/g8_race_screen.py in round 3.  No product path selects this epilogue on gemm8: the head + MSE runs on gemm_persist.)
                 float* red = reinterpret_cast<float*>(smem + 2 * TILE);
-                if (lane == 0) red[wave * (4 * WN)] = w;
+                if (lane == 0) red[wave * (16 * WN)] = w;
                 asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
                 asm volatile("s_barrier" ::: "memory");
                 if (tid == 0) {
                     float s = 0.f;
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) s += red[q * (4 * WN)];
+                    for (int q = 0; q < 8; ++q) s += red[q * (16 * WN)];
                     p.partial[cu.tile] = s;
                 }
             }
@@ -657,14 +714,16 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const GemmGroup g, const 
                 float v = rsum[mh];
                 v += __shfl_xor(v, 16, 64);
                 v += __shfl_xor(v, 32, 64);
-                const int m = m0 + wm * 128 + 16 * (4 * mh + wn) + lane;
-                if ((lane >> 4) == 0 && m < p.M) atomicAdd(p.rowsum + m, v * alpha);
+                const int m = m0 + wm * WMR + 16 * (TMH * mh + wn) + lane;
+                if (wn < TMH && (lane >> 4) == 0 && m < p.M) atomicAdd(p.rowsum + m, v * alpha);
             }
         }
         uid += nslots;
         if (uid >= x_hi) break;
-        decode_unit<BN>(g, uid, cu);
-        after_epi = (EC == 2 && atomic) ? 0 : EC == 0 ? nstores : -1;
+        decode_unit<BM, BN>(g, uid, cu);
+        // (atomics and the 384-wide tile's dword stores queue behind the prefetch like any store: the plain counted wait of the next
+        //  K tile then waits for them as well - once per unit, conservative and exact)
+        after_epi = ((EC == 2 && atomic) || BN == 384) ? 0 : EC == 0 ? nstores : -1;
     }
     // drain the out-of-range tail of the stream, then pay back the stagger barrier
     wait_vmcnt<0>();
@@ -672,17 +731,19 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const GemmGroup g, const 
 }
 
 // ------------------------------------------------------------------ host side
-template <int BN, bool AT, bool BT, int EC>
+template <int BM, int BN, bool AT, bool BT, int EC>
 static int launch_gemm8_one(const GemmGroup& g, int total, hipStream_t stream) {
-    // two K-tile slots + the epilogue region: 16 parked rows per wave (classes 1-3) or the bias copy of class 0 (32 KiB: N <= 8192)
-    constexpr size_t lds = 2 * (size_t)(256 + BN) * 64 * 2 + (EC == 0 ? (size_t)32768 : (size_t)8 * 16 * (BN / 4) * 4);
+    // two K-tile slots + the epilogue region: 16 parked rows per wave (classes 1-3; 16 x 48 for the 384-wide tile) or the bias
+    // copy of class 0 (32 KiB: N <= 8192)
+    constexpr size_t lds = 2 * (size_t)(BM + BN) * 64 * 2 + (EC == 0 ? (size_t)32768 : BN == 384 ? (size_t)8 * 16 * 48 * 4 : (size_t)8 * 16 * (BN / 4) * 4);
+    static_assert(lds <= 160 * 1024, "LDS per CU");
     if (dry_run().on) {
-        snprintf(dry_run().name, sizeof(dry_run().name), "bvc::gemm8_kernel<%d, %s, %s, %d>", BN, AT ? "true" : "false", BT ? "true" : "false", EC);
+        snprintf(dry_run().name, sizeof(dry_run().name), "bvc::gemm8_kernel<%d, %d, %s, %s, %d>", BM, BN, AT ? "true" : "false", BT ? "true" : "false", EC);
         return BVC_OK;
     }
     static bool attr_set = false;
     if (!attr_set) {
-        BVC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm8_kernel<BN, AT, BT, EC>),
+        BVC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm8_kernel<BM, BN, AT, BT, EC>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
@@ -696,7 +757,7 @@ static int launch_gemm8_one(const GemmGroup& g, int total, hipStream_t stream) {
         if (ncu < 8) ncu = 8;
     }
     const int grid = total < ncu ? ((total + 7) / 8) * 8 : ncu;      // one workgroup per CU, a multiple of the 8 XCDs
-    hipLaunchKernelGGL((gemm8_kernel<BN, AT, BT, EC>), dim3(grid), dim3(512), lds, stream, g, total);
+    hipLaunchKernelGGL((gemm8_kernel<BM, BN, AT, BT, EC>), dim3(grid), dim3(512), lds, stream, g, total);
     BVC_CHECK_HIP(hipGetLastError());
     return BVC_OK;
 }
@@ -711,7 +772,8 @@ static int epi_class(int epi, GemmLayout layout) {
     }
 }
 
-// Launcher hook used by launch_gemm (gemm.hip): bn = 256 / 128.  Returns BVC_OK after launching, 1 when the group is not eligible.
+// Launcher hook used by launch_gemm (gemm.hip): bn = 256 / 128 (256-row tiles) or 384 (128-row tiles, weight gradients only).
+// Returns BVC_OK after launching, 1 when the group is not eligible.
 int launch_gemm8(const GemmGroup& g, GemmLayout layout, int bn, hipStream_t stream) {
     const int total = g.tile_start[g.nprob];
     int ec = -2;
@@ -729,7 +791,11 @@ int launch_gemm8(const GemmGroup& g, GemmLayout layout, int bn, hipStream_t stre
         if (c == 0 && (g.nprob != 1 || (size_t)((p.N + bn - 1) / bn) * bn * 4 > (size_t)32768)) return 1;
     }
     if (total <= 0) return 1;
-#define BVC_G8(BN_, AT_, BT_, EC_) return launch_gemm8_one<BN_, AT_, BT_, EC_>(g, total, stream)
+#define BVC_G8(BN_, AT_, BT_, EC_) return launch_gemm8_one<256, BN_, AT_, BT_, EC_>(g, total, stream)
+    if (bn == 384) {
+        if (layout != GEMM_TN) return 1;
+        return launch_gemm8_one<128, 384, true, true, 2>(g, total, stream);
+    }
     if (layout == GEMM_NT) {
         if (ec == 0) { if (bn == 256) BVC_G8(256, false, false, 0); else BVC_G8(128, false, false, 0); }
         if (ec == 3) { if (bn == 256) BVC_G8(256, false, false, 3); else BVC_G8(128, false, false, 3); }

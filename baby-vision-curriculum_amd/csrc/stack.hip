@@ -156,21 +156,43 @@ int plan_dw(GemmProblem* g, int n) {
     // 256 x 128 unsplit 218 us vs the 128 x 128 kernel 220 us; decoder layer 256 x 256 split 6 (228 units) 549 us vs 626 us.
     const int g8 = options().gemm8;
     if (g8 >= 0) {
-        bool ok = true;
-        double flops = 0.0;
+        bool ok = true, by384 = true;
+        double flops = 0.0, outs = 0.0;
+        int units256 = 0, units384 = 0;
         for (int i = 0; i < n; ++i) {
             ok = ok && g[i].epi == EPI_F32 && g[i].a_bytes < 0x80000000u && g[i].b_bytes < 0x80000000u;
+            by384 = by384 && g[i].N % 384 == 0 && g[i].M % 128 == 0;
             flops += 2.0 * g[i].M * g[i].N * g[i].K;
+            outs += (double)g[i].M * g[i].N;
+            units256 += ((g[i].M + 255) / 256) * ((g[i].N + 255) / 256);
+            units384 += ((g[i].M + 127) / 128) * ((g[i].N + 383) / 384);
         }
-        // short launches stay on the 128 x 128 kernel (at 16 clips: encoder layer 53 vs 85 us, decoder layer 139 vs 151 us,
-        // profiles/r02_e_gemm8_ab_b16.txt): one workgroup per CU needs a long stream to amortise its prologue and tail
+        // Widths that are multiples of 384 but not of 256 (decoder, JEPA predictor: 384 / 1152 / 1536) leave 256 x 256 tiles partly
+        // empty - the four weight gradients of a VideoMAE decoder layer fill 71 % of 38 such tiles and 100 % of 36 tiles of 128 x 384
+        // (tile config 12).  Taken when the 256-wide tiling would execute >= 1.2x the MFMA work of the outputs.  K split: the fewest
+        // splits that give every CU one unit (units x split as close below a multiple of 256 as it gets), at least 16 K tiles each.
+        const bool long_enough = g8 > 0 ? ksteps >= 2 : (ksteps >= 16 && flops >= 140e9);
+        if (ok && by384 && long_enough && units256 * 65536.0 >= 1.2 * outs) {
+            const int smax = std::max(1, std::min(16, ksteps / (g8 > 0 ? 2 : 16)));
+            int best = 1;
+            double best_cost = 1e300;
+            for (int sp = 1; sp <= smax; ++sp) {
+                const int rounds = (units384 * sp + 255) / 256;
+                const double cost = (double)rounds * ((ksteps + sp - 1) / sp) + 4.0 * rounds;     // K tiles on the critical path + an epilogue per round
+                if (cost < best_cost * 0.999) { best_cost = cost; best = sp; }
+            }
+            if (units384 * best >= (g8 > 0 ? 1 : 160)) {
+                for (int i = 0; i < n; ++i) g[i].split_k = best;
+                return 12;
+            }
+        }
         if (ok && g8 > 0 && ksteps >= 2) {          // forced (tests, A/B tools): 256 x 256 tiles, K split for ~230 units as below
-            int units = 0;
-            for (int i = 0; i < n; ++i) units += ((g[i].M + 255) / 256) * ((g[i].N + 255) / 256);
-            const int split = std::max(1, std::min((232 + units / 2) / units, ksteps / 2));
+            const int split = std::max(1, std::min((232 + units256 / 2) / units256, ksteps / 2));
             for (int i = 0; i < n; ++i) g[i].split_k = split;
             return 10;
         }
+        // short launches stay on the 128 x 128 kernel (at 16 clips: encoder layer 53 vs 85 us, decoder layer 139 vs 151 us,
+        // profiles/r02_e_gemm8_ab_b16.txt): one workgroup per CU needs a long stream to amortise its prologue and tail
         if (ok && ksteps >= 16 && flops >= 140e9) {
             for (int t = 0; t < 2; ++t) {            // prefer the bigger tile when it still fills the chip
                 const int bnw = t == 0 ? 256 : 128;

@@ -135,6 +135,8 @@ def main():
                          "16 clips (slurm_dev_def.bash:52), so the default is 256 (~40 GB); BASELINE.md lists 16 and 64 as well")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-by-batch", action="store_true", help="skip the 64- and 16-clip legs reported as `by_batch`")
+    ap.add_argument("--no-probe", action="store_true",
+                    help="skip the per-kernel probes behind `roofline.kernel` / `roofline.kernels` (profiling runs: only the timed steps' kernels)")
     ap.add_argument("--torch-sgd", action="store_true", help="use torch.optim.SGD instead of the fused HIP update")
     ap.add_argument("--per-step", action="store_true", help="diagnostic: per-step HIP-event and host-enqueue times to stderr")
     ap.add_argument("--bucket-mb", type=float, default=25.0, help="gradient all-reduce bucket size of the data-parallel wrapper")
@@ -331,7 +333,8 @@ def main():
         if world == 1:
             # the dominant kernel of the step = the kernel instantiation with the largest time share, from per-product launches
             # timed alone in this run and named as rocprofv3 names them (compare: profiles/r03_*_roofline_table_b256.txt row 1)
-            line["roofline"].update(kernel_roofline(bvc, B, dev))
+            if not args.no_probe:
+                line["roofline"].update(kernel_roofline(bvc, B, dev))
             if by_batch:
                 line["by_batch"] = by_batch
         if comm is not None:

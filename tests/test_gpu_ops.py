@@ -625,7 +625,8 @@ def test_bvc_gradscaler_matches_torch_gradscaler():
 
 
 # --------------------------------------------------------------------------- GEMM, 256-row persistent kernel (csrc/gemm8.hip)
-# tile 10 = 256 x 256 (bf16-output epilogues and weight gradients), tile 11 = 256 x 128 (every epilogue)
+# tile 10 = 256 x 256 (bf16-output epilogues and weight gradients), tile 11 = 256 x 128 (every epilogue),
+# tile 12 = 128 x 384 (weight gradients whose widths are multiples of 384: decoder, JEPA predictor)
 G8_SHAPES = [(256, 256, 128), (200, 192, 256), (520, 384, 384), (136, 72, 192), (2560, 768, 768), (1000, 1152, 64), (10240, 2304, 256)]
 
 
@@ -640,7 +641,7 @@ def test_gemm8_f32(layout, M, N, K):
     A = G.bf16_randn(*sa, seed=1)
     B = G.bf16_randn(*sb, seed=2)
     ref = _ref_gemm(A, B, layout)
-    for tile in (10, 11):
+    for tile in (10, 11, 12) if layout == G.TN else (10, 11):     # 12 = 128 x 384 tiles: weight gradients only
         C = torch.full((M, N), float("nan"), device=dev)
         G.run_gemm([G.gemm_desc(A, B, M, N, K, G.EPI["F32"], C)], layout, tile)
         torch.cuda.synchronize()
@@ -724,8 +725,8 @@ def test_gemm8_epilogues(tile):
     torch.cuda.synchronize()
 
 
-@pytest.mark.parametrize("tile", [10, 11])
-@pytest.mark.parametrize("split", [1, 3, 4])
+@pytest.mark.parametrize("tile", [10, 11, 12])
+@pytest.mark.parametrize("split", [1, 3, 4, 7])
 def test_gemm8_weight_gradient_group(tile, split):
     # the four weight gradients of one layer in one launch, fused bias gradients, split-K atomics, ragged token count
     Mtok, D, I = 5000, 384, 1536

@@ -66,6 +66,8 @@ PY
     micro) run micro 400 python tools/microbench.py ;;
     racescreen) run racescreen 500 python tools/persist_race_screen.py ;;
     g8race) run g8race 600 python tools/g8_race_screen.py ;;
+    lossdbg) run lossdbg 300 python tools/debug/g8_loss_dbg.py ;;
+    dwab)  run dwab 400 python tools/dw_tile_ab.py ;;
     gemmdbg) run gemmdbg 300 python tools/gemm_dbg.py ;;
     ksweep) run ksweep 400 python tools/gemm_ksweep.py ;;
     dwsweep) run dwsweep 400 python tools/dw_sweep.py ;;
@@ -76,18 +78,18 @@ PY
     encode) run encode 300 python tools/bench_encode.py ;;
     simclr) run simclr 400 python tools/bench_simclr.py ;;
     prof)  rm -rf $OUT/prof; cd /tmp
-           run prof 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --batch ${BVC_BATCH:-256}
+           run prof 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-by-batch --no-probe --batch ${BVC_BATCH:-256}
            cd $R
            find $OUT/prof -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/kernel_stats.csv
            find $OUT/prof -name "*kernel_trace.csv" -size +20M -delete ;;
     traffic) rm -rf $OUT/pmct; cd /tmp
-           run traffic_rd 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmct/rd -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --batch ${BVC_BATCH:-256}
-           run traffic_wr 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmct/wr -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --batch ${BVC_BATCH:-256}
+           run traffic_rd 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmct/rd -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-by-batch --no-probe --batch ${BVC_BATCH:-256}
+           run traffic_wr 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmct/wr -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-by-batch --no-probe --batch ${BVC_BATCH:-256}
            cd $R
            run traffic 60 python tools/pmc_traffic.py $OUT/pmct/rd $OUT/pmct/wr 3 ${BVC_BATCH:-256} $OUT/traffic_b${BVC_BATCH:-256}.json
            find $OUT/pmct -name "*.csv" -size +5M -delete ;;
     mfma)  rm -rf $OUT/pmcm; cd /tmp
-           run mfma_pmc 400 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES --output-format csv -d $OUT/pmcm -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --batch ${BVC_BATCH:-256}
+           run mfma_pmc 400 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES --output-format csv -d $OUT/pmcm -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-by-batch --no-probe --batch ${BVC_BATCH:-256}
            cd $R
            run mfma_table 60 python tools/pmc_mfma_step.py $OUT/pmcm 3 $OUT/mfma_busy_b${BVC_BATCH:-256}.txt
            find $OUT/pmcm -name "*.csv" -size +5M -delete ;;

@@ -171,7 +171,9 @@ int plan_dw(GemmProblem* g, int n) {
         // empty - the four weight gradients of a VideoMAE decoder layer fill 71 % of 38 such tiles and 100 % of 36 tiles of 128 x 384
         // (tile config 12).  Taken when the 256-wide tiling would execute >= 1.2x the MFMA work of the outputs.  K split: the fewest
         // splits that give every CU one unit (units x split as close below a multiple of 256 as it gets), at least 16 K tiles each.
-        const bool long_enough = g8 > 0 ? ksteps >= 2 : (ksteps >= 16 && flops >= 140e9);
+        // (same-process A/B, profiles/r03_b_dw_tile12_ab_b{16,64,256}.txt: decoder layer group 1522 vs 2312 us at 256 clips, 383 vs
+        //  558 at 64, 125 vs 139 (the 128 x 128 kernel) at 16 - it needs a shorter stream than the 256 x 256 tile to pay off)
+        const bool long_enough = g8 > 0 ? ksteps >= 2 : (ksteps >= 16 && flops >= 80e9);
         if (ok && by384 && long_enough && units256 * 65536.0 >= 1.2 * outs) {
             const int smax = std::max(1, std::min(16, ksteps / (g8 > 0 ? 2 : 16)));
             int best = 1;

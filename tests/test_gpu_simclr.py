@@ -208,6 +208,81 @@ def test_simclr_vit_b_composition_matches_oracle():
     assert (num / den) ** 0.5 < 1.2e-1, (num / den) ** 0.5
 
 
+def test_simclr_vit_b_gradients_at_64_pairs():
+    """Config-5 gradient parity at a meaningful size: 64 pairs (128 images of 224^2) through SimCLRViT (ViT-B/16 trunk, token
+    mean, 768-wide head, info_nce_loss), EVERY trunk and head gradient tensor compared with the f32 oracle.
+
+    The one ill-conditioned point of this composition is the head's ReLU: a pre-activation within bf16 noise of zero has its
+    gate decided by rounding, and 1/T = 10 amplifies the resulting gradient difference (round 2 measured 7.7e-2 aggregate at 4
+    pairs and could not say how much of it was kernels).  Here the two causes are separated:
+      (1) per-tensor bar, 3e-2: against the f32 oracle evaluated AT THE DEVICE'S GATE PATTERN - same f32 trunk, same loss, the
+          head's ReLU replaced by the 0/1 mask the device's own first GEMM produced.  What is left is bf16 operand rounding;
+      (2) reported next to it: the fraction of gates that differ from the pure f32 oracle's and the aggregate gradient error
+          against that oracle - the measured flipped-gate bound, which the kernels cannot influence.
+    Loss (1e-3) and features (2e-2) stay pinned against the pure f32 oracle."""
+    from oracle import jepa_oracle as jo
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    cfg = jo.JepaConfig(num_frames=1)          # ViT-B/16, 224^2, one frame
+    B, D = 64, cfg.embed_dim
+    enc_p = jo.make_params(jo.encoder_shapes(cfg), cfg, seed=4)
+    head_p = so.head_params(D, D, seed=9)
+    g = torch.Generator().manual_seed(23)
+    imgs = torch.randn(2 * B, cfg.in_chans, cfg.image_size, cfg.image_size, generator=g)
+
+    model = bvc.simclr.SimCLRViT("vit_base", image_size=224)
+    model.trunk.load_state_dict(enc_p)
+    model.fc.load_state_dict(head_p)
+    model.to(dev).train()
+    x = imgs.to(dev)
+    out = model(x)
+    loss = bvc.simclr.global_info_nce_loss(0.1, bvc.simclr.make_masks(B, dev), out)
+    loss.backward()
+    with torch.no_grad():      # the device's gate pattern: its own pooled features through its own first GEMM (bias + ReLU epilogue)
+        pooled_dev = bvc.jepa.token_mean(model.trunk(x.unsqueeze(1)))
+        ops = bvc._ops
+        xb, w1b = ops.cast_bf16(pooled_dev), ops.cast_bf16(model.fc._modules["0"].weight.detach())
+        h_dev = torch.empty((2 * B, D), dtype=torch.bfloat16, device=dev)
+        ops.gemm(ops.gemm_desc(xb, w1b, 2 * B, D, D, ops.EPI["RELU"], h_dev, bias=model.fc._modules["0"].bias.detach().float()), ops.NT)
+        gate = (h_dev.float() > 0).float().cpu()
+    torch.cuda.synchronize()
+
+    def oracle(gate_mask):
+        ep = {k: v.clone().requires_grad_(k != "pos_embed") for k, v in enc_p.items()}
+        hp = {k: v.clone().requires_grad_(True) for k, v in head_p.items()}
+        pooled = jo.encoder_forward(cfg, ep, imgs.unsqueeze(1)).mean(1)
+        pre = torch.nn.functional.linear(pooled, hp["0.weight"], hp["0.bias"])
+        hid = torch.relu(pre) if gate_mask is None else pre * gate_mask
+        feats = torch.nn.functional.linear(hid, hp["2.weight"], hp["2.bias"])
+        ls = so.info_nce_loss(0.1, so.make_masks(B), feats)
+        ls.backward()
+        grads = {k: v.grad for k, v in ep.items() if v.grad is not None}
+        grads.update({"fc." + k: v.grad for k, v in hp.items()})
+        return float(ls), feats.detach(), (pre.detach() > 0).float(), grads
+
+    ref_loss, ref_feats, ref_gate, ref_grads = oracle(None)
+    _gl, _gf, _gg, gate_grads = oracle(gate)
+    assert abs(float(loss) - ref_loss) / abs(ref_loss) < 1e-3, (float(loss), ref_loss)
+    assert G.rel_err(out.detach().cpu(), ref_feats) < 2e-2
+    flipped = float((gate != ref_gate).float().mean())
+
+    got = {k: p.grad.detach().float().cpu() for k, p in model.trunk.named_parameters() if p.grad is not None}
+    got.update({"fc." + k: p.grad.detach().float().cpu() for k, p in model.fc.named_parameters()})
+    assert set(got) == set(gate_grads)
+    gmax = max(float(v.norm()) for v in gate_grads.values())
+    errs = {k: float((got[k] - r).norm() / (r.norm() + 1e-3 * gmax)) for k, r in gate_grads.items()}
+    worst = max(errs.items(), key=lambda kv: kv[1])
+
+    def aggregate(ref):
+        num = sum(float((got[k] - ref[k]).double().pow(2).sum()) for k in ref)
+        return (num / sum(float(ref[k].double().pow(2).sum()) for k in ref)) ** 0.5
+
+    print(f"SimCLR ViT-B, 64 pairs: {len(got)} gradient tensors, worst per-tensor rel L2 vs the oracle at the device's gates "
+          f"{worst[1]:.2e} ({worst[0]}), aggregate {aggregate(gate_grads):.2e}; ReLU gates differing from the pure f32 oracle's: "
+          f"{100 * flipped:.3f} % -> aggregate vs the pure f32 oracle {aggregate(ref_grads):.2e} (the flipped-gate bound)")
+    over = {k: round(e, 4) for k, e in errs.items() if e >= 3e-2}
+    assert not over, over
+
+
 def test_token_mean_forward_backward():
     x = torch.randn(5, 37, 192, device=dev, requires_grad=True)
     y = bvc.jepa.token_mean(x)

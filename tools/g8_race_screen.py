@@ -1,4 +1,4 @@
-"""Race screen for the 256-row persistent GEMM (csrc/gemm8.hip, tile configs 10 / 11): many back-to-back launches of every
+"""Race screen for the persistent one-workgroup-per-CU GEMM (csrc/gemm8.hip, tile configs 10 / 11 / 12): many back-to-back launches of every
 epilogue class (0: BF16 / GELU / RELU in registers, un-drained stores; 3: GELU'; 1: f32 outputs with side inputs, LOSS; 2: weight
 gradients, unsplit and as the split-K group of a layer) while streaming kernels keep the memory system busy.
 
@@ -28,7 +28,8 @@ cases = [
     (G.NN, "DGELU", 50176, 1536, 384, 10), (G.NN, "DGELU", 20480, 3072, 768, 10),
     (G.NT, "RESID", 40960, 768, 3072, 10), (G.NT, "RESID", 100352, 384, 1536, 11), (G.NT, "F32", 20000, 776, 1536, 10),
     (G.NT, "LOSS", 45056, 1536, 384, 10),
-    (G.TN, "F32", 768, 3072, 20480, 10), (G.TN, "F32", 1152, 384, 50176, 11),
+    (G.TN, "F32", 768, 3072, 20480, 10), (G.TN, "F32", 1152, 384, 50176, 11), (G.TN, "F32", 1152, 1536, 30080, 12),
+    (G.TN, "F32", 392, 776, 9000, 12),
 ]
 bad = 0
 noise = torch.randn(64 << 20, device=dev)
@@ -91,7 +92,8 @@ for layout, epi, M, N, K, tile in cases:
     bad += mism
 
 # the split-K weight-gradient group of one layer (class 2 with atomics), encoder and decoder widths, as plan_dw launches it
-for tag, M, D, I, tile, split in (("enc", 20480, 768, 3072, 10, 2), ("dec", 100352, 384, 1536, 10, 6), ("dec", 50176, 384, 1536, 11, 4)):
+for tag, M, D, I, tile, split in (("enc", 20480, 768, 3072, 10, 2), ("dec", 100352, 384, 1536, 10, 6), ("dec", 50176, 384, 1536, 11, 4),
+                                 ("dec", 100352, 384, 1536, 12, 7), ("dec", 25088, 384, 1536, 12, 7)):
     dy, act = G.bf16_randn(M, D, seed=7), G.bf16_randn(M, I, seed=8)
     dh, ln2 = G.bf16_randn(M, I, seed=9), G.bf16_randn(M, D, seed=10)
     dqkv = G.bf16_randn(M, 3 * D, seed=11)

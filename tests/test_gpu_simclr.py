@@ -210,17 +210,23 @@ def test_simclr_vit_b_composition_matches_oracle():
 
 def test_simclr_vit_b_gradients_at_64_pairs():
     """Config-5 gradient parity at a meaningful size: 64 pairs (128 images of 224^2) through SimCLRViT (ViT-B/16 trunk, token
-    mean, 768-wide head, info_nce_loss), EVERY trunk and head gradient tensor compared with the f32 oracle.
+    mean, 768-wide head, info_nce_loss), EVERY gradient tensor (148 trunk + 4 head) against the f32 oracle.
 
-    The one ill-conditioned point of this composition is the head's ReLU: a pre-activation within bf16 noise of zero has its
-    gate decided by rounding, and 1/T = 10 amplifies the resulting gradient difference (round 2 measured 7.7e-2 aggregate at 4
-    pairs and could not say how much of it was kernels).  Here the two causes are separated:
-      (1) per-tensor bar, 3e-2: against the f32 oracle evaluated AT THE DEVICE'S GATE PATTERN - same f32 trunk, same loss, the
-          head's ReLU replaced by the 0/1 mask the device's own first GEMM produced.  What is left is bf16 operand rounding;
-      (2) reported next to it: the fraction of gates that differ from the pure f32 oracle's and the aggregate gradient error
-          against that oracle - the measured flipped-gate bound, which the kernels cannot influence.
-    Loss (1e-3) and features (2e-2) stay pinned against the pure f32 oracle."""
+    End to end this composition is ill-conditioned in two places, and neither is a kernel property: (a) the head's ReLU - a
+    pre-activation within bf16 noise of zero has its gate decided by rounding; (b) the loss - its gradient carries the softmax
+    weights exp(cos / T - lse) with 1 / T = 10, so bf16-level differences in the features move those weights by several per cent
+    (and the head's second bias gradient is a column sum of exactly those, nearly cancelling, terms).  Measured here: 0.12 % of
+    the gates differ from the pure f32 oracle's and the end-to-end gradient is 1.8e-1 away from it in aggregate (printed below;
+    round 2 accepted 1.2e-1 at 4 pairs without separating anything).  So the chain is cut at every ill-conditioned link and each
+    stage is held to the oracle evaluated AT THE DEVICE'S OWN STAGE INPUT - which is what "the kernels compute what the
+    reference computes" means for a chain like this:
+      S1 trunk forward            pooled features                                   2e-2   (pure f32 oracle, end to end)
+      S2 head forward             features, at the device's pooled features         2e-2   (+ end to end: 2e-2)
+      S3 loss and its gradient    at the device's features                          1e-3 / 3e-2   (+ loss end to end: 1e-3)
+      S4 head backward            at the device's pooled features, ReLU gates and d loss / d features: 4 head gradients, d pooled   3e-2
+      S5 trunk backward           the f32 oracle trunk driven by the device's d loss / d pooled: all 148 trunk gradients          3e-2"""
     from oracle import jepa_oracle as jo
+    F = torch.nn.functional
     torch.set_num_threads(min(16, os.cpu_count() or 1))
     cfg = jo.JepaConfig(num_frames=1)          # ViT-B/16, 224^2, one frame
     B, D = 64, cfg.embed_dim
@@ -234,51 +240,80 @@ def test_simclr_vit_b_gradients_at_64_pairs():
     model.fc.load_state_dict(head_p)
     model.to(dev).train()
     x = imgs.to(dev)
-    out = model(x)
+    # SimCLRViT.forward, spelled out so that the stage inputs and their gradients can be read
+    pooled_dev = bvc.jepa.token_mean(model.trunk(x.unsqueeze(1)))
+    pooled_dev.retain_grad()
+    out = model.fc(pooled_dev)
+    out.retain_grad()
     loss = bvc.simclr.global_info_nce_loss(0.1, bvc.simclr.make_masks(B, dev), out)
     loss.backward()
-    with torch.no_grad():      # the device's gate pattern: its own pooled features through its own first GEMM (bias + ReLU epilogue)
-        pooled_dev = bvc.jepa.token_mean(model.trunk(x.unsqueeze(1)))
+    with torch.no_grad():      # the device's gate pattern: its own first head GEMM (bias + ReLU epilogue) on its own pooled features
         ops = bvc._ops
-        xb, w1b = ops.cast_bf16(pooled_dev), ops.cast_bf16(model.fc._modules["0"].weight.detach())
+        xb, w1b = ops.cast_bf16(pooled_dev.detach()), ops.cast_bf16(model.fc._modules["0"].weight.detach())
         h_dev = torch.empty((2 * B, D), dtype=torch.bfloat16, device=dev)
         ops.gemm(ops.gemm_desc(xb, w1b, 2 * B, D, D, ops.EPI["RELU"], h_dev, bias=model.fc._modules["0"].bias.detach().float()), ops.NT)
         gate = (h_dev.float() > 0).float().cpu()
     torch.cuda.synchronize()
-
-    def oracle(gate_mask):
-        ep = {k: v.clone().requires_grad_(k != "pos_embed") for k, v in enc_p.items()}
-        hp = {k: v.clone().requires_grad_(True) for k, v in head_p.items()}
-        pooled = jo.encoder_forward(cfg, ep, imgs.unsqueeze(1)).mean(1)
-        pre = torch.nn.functional.linear(pooled, hp["0.weight"], hp["0.bias"])
-        hid = torch.relu(pre) if gate_mask is None else pre * gate_mask
-        feats = torch.nn.functional.linear(hid, hp["2.weight"], hp["2.bias"])
-        ls = so.info_nce_loss(0.1, so.make_masks(B), feats)
-        ls.backward()
-        grads = {k: v.grad for k, v in ep.items() if v.grad is not None}
-        grads.update({"fc." + k: v.grad for k, v in hp.items()})
-        return float(ls), feats.detach(), (pre.detach() > 0).float(), grads
-
-    ref_loss, ref_feats, ref_gate, ref_grads = oracle(None)
-    _gl, _gf, _gg, gate_grads = oracle(gate)
-    assert abs(float(loss) - ref_loss) / abs(ref_loss) < 1e-3, (float(loss), ref_loss)
-    assert G.rel_err(out.detach().cpu(), ref_feats) < 2e-2
-    flipped = float((gate != ref_gate).float().mean())
-
     got = {k: p.grad.detach().float().cpu() for k, p in model.trunk.named_parameters() if p.grad is not None}
     got.update({"fc." + k: p.grad.detach().float().cpu() for k, p in model.fc.named_parameters()})
-    assert set(got) == set(gate_grads)
-    gmax = max(float(v.norm()) for v in gate_grads.values())
-    errs = {k: float((got[k] - r).norm() / (r.norm() + 1e-3 * gmax)) for k, r in gate_grads.items()}
-    worst = max(errs.items(), key=lambda kv: kv[1])
+    pooled_in, feats_in = pooled_dev.detach().cpu(), out.detach().cpu()
+    dpooled_dev, dfeats_dev = pooled_dev.grad.detach().float().cpu(), out.grad.detach().float().cpu()
+    masks = so.make_masks(B)
+
+    def head(pooled, hp, gate_mask):
+        pre = F.linear(pooled, hp["0.weight"], hp["0.bias"])
+        hid = torch.relu(pre) if gate_mask is None else pre * gate_mask
+        return F.linear(hid, hp["2.weight"], hp["2.bias"]), (pre.detach() > 0).float()
+
+    # pure f32 oracle, end to end: S1, the end-to-end pins, the end-to-end bound
+    ep = {k: v.clone().requires_grad_(k != "pos_embed") for k, v in enc_p.items()}
+    hp = {k: v.clone().requires_grad_(True) for k, v in head_p.items()}
+    pooled_ref = jo.encoder_forward(cfg, ep, imgs.unsqueeze(1)).mean(1)
+    ref_feats, ref_gate = head(pooled_ref, hp, None)
+    ref_loss = so.info_nce_loss(0.1, masks, ref_feats)
+    ref_loss.backward(retain_graph=True)
+    e2e = {k: v.grad.clone() for k, v in ep.items() if v.grad is not None}
+    e2e.update({"fc." + k: v.grad.clone() for k, v in hp.items()})
+    rep = {"S1 pooled": G.rel_err(pooled_in, pooled_ref.detach()), "features end to end": G.rel_err(feats_in, ref_feats.detach()),
+           "loss end to end": abs(float(loss) - float(ref_loss)) / abs(float(ref_loss))}
+    flipped = float((gate != ref_gate).float().mean())
+    # S5: the oracle trunk's backward from the device's upstream gradient
+    for v in ep.values():
+        v.grad = None
+    pooled_ref.backward(dpooled_dev)
+    want = {k: v.grad.clone() for k, v in ep.items() if v.grad is not None}
+    # S2 + S4: the oracle head at the device's pooled features and gates, driven by the device's d loss / d features
+    hpa = {k: v.clone().requires_grad_(True) for k, v in head_p.items()}
+    pin = pooled_in.clone().requires_grad_(True)
+    feats_a, _ = head(pin, hpa, gate)
+    rep["S2 features"] = G.rel_err(feats_in, feats_a.detach())
+    feats_a.backward(dfeats_dev)
+    want.update({"fc." + k: v.grad.clone() for k, v in hpa.items()})
+    rep["S4 d pooled"] = G.rel_err(dpooled_dev, pin.grad)
+    # S3: the oracle loss at the device's features
+    fin = feats_in.clone().requires_grad_(True)
+    loss_c = so.info_nce_loss(0.1, masks, fin)
+    loss_c.backward()
+    rep["S3 loss"] = abs(float(loss) - float(loss_c)) / abs(float(loss_c))
+    rep["S3 d features"] = G.rel_err(dfeats_dev, fin.grad)
+
+    assert set(got) == set(want) == set(e2e)
+    gmax = max(float(v.norm()) for v in want.values())
+    errs = {k: float((got[k] - r).norm() / (r.norm() + 1e-3 * gmax)) for k, r in want.items()}
+    worst_t = max(((k, e) for k, e in errs.items() if not k.startswith("fc.")), key=lambda kv: kv[1])
+    worst_h = max(((k, e) for k, e in errs.items() if k.startswith("fc.")), key=lambda kv: kv[1])
 
     def aggregate(ref):
         num = sum(float((got[k] - ref[k]).double().pow(2).sum()) for k in ref)
         return (num / sum(float(ref[k].double().pow(2).sum()) for k in ref)) ** 0.5
 
-    print(f"SimCLR ViT-B, 64 pairs: {len(got)} gradient tensors, worst per-tensor rel L2 vs the oracle at the device's gates "
-          f"{worst[1]:.2e} ({worst[0]}), aggregate {aggregate(gate_grads):.2e}; ReLU gates differing from the pure f32 oracle's: "
-          f"{100 * flipped:.3f} % -> aggregate vs the pure f32 oracle {aggregate(ref_grads):.2e} (the flipped-gate bound)")
+    print(f"SimCLR ViT-B, 64 pairs, {len(got)} gradient tensors, staged: " + ", ".join(f"{k} {v:.2e}" for k, v in rep.items()) +
+          f"; S5 worst trunk tensor {worst_t[1]:.2e} ({worst_t[0]}), S4 worst head tensor {worst_h[1]:.2e} ({worst_h[0]}), staged aggregate "
+          f"{aggregate(want):.2e}; end to end against the pure f32 oracle: {100 * flipped:.3f} % of the ReLU gates differ, gradient aggregate "
+          f"{aggregate(e2e):.2e} (the bound set by conditioning: gates, and 1 / T = 10 on bf16-level feature differences)")
+    assert rep["S1 pooled"] < 2e-2 and rep["features end to end"] < 2e-2 and rep["S2 features"] < 2e-2
+    assert rep["loss end to end"] < 1e-3 and rep["S3 loss"] < 1e-3
+    assert rep["S3 d features"] < 3e-2 and rep["S4 d pooled"] < 3e-2
     over = {k: round(e, 4) for k, e in errs.items() if e >= 3e-2}
     assert not over, over
 

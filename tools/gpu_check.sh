@@ -68,6 +68,7 @@ PY
     g8race) run g8race 600 python tools/g8_race_screen.py ;;
     probe_step) run probe_step_b${BVC_BATCH:-256} 300 python tools/step_probe.py ;;
     simclr64) run simclr64 900 python -m pytest tests/test_gpu_simclr.py -m gpu -q -x -s -p no:cacheprovider -k "64_pairs" ;;
+    attntests) run attntests 400 python -m pytest tests/test_gpu_ops.py -m gpu -q -x -p no:cacheprovider -k attention ;;
     lossdbg) run lossdbg 300 python tools/debug/g8_loss_dbg.py ;;
     dwab)  run dwab 400 python tools/dw_tile_ab.py ;;
     gemmdbg) run gemmdbg 300 python tools/gemm_dbg.py ;;

@@ -223,7 +223,7 @@ def test_simclr_vit_b_gradients_at_64_pairs():
       S1 trunk forward            pooled features                                   2e-2   (pure f32 oracle, end to end)
       S2 head forward             features, at the device's pooled features         2e-2   (+ end to end: 2e-2)
       S3 loss and its gradient    at the device's features                          1e-3 / 3e-2   (+ loss end to end: 1e-3)
-      S4 head backward            at the device's pooled features, ReLU gates and d loss / d features: 4 head gradients, d pooled   3e-2
+      S4 head backward            at the device's pooled features, ReLU gates and d loss / d features, bf16 operands: 4 head gradients, d pooled   3e-2
       S5 trunk backward           the f32 oracle trunk driven by the device's d loss / d pooled: all 148 trunk gradients          3e-2"""
     from oracle import jepa_oracle as jo
     F = torch.nn.functional
@@ -283,11 +283,17 @@ def test_simclr_vit_b_gradients_at_64_pairs():
     pooled_ref.backward(dpooled_dev)
     want = {k: v.grad.clone() for k, v in ep.items() if v.grad is not None}
     # S2 + S4: the oracle head at the device's pooled features and gates, driven by the device's d loss / d features
+    # (S4 on the operands the MFMAs consume - pooled features, both weights, the hidden activation and the upstream gradient rounded
+    #  to bf16, f32 accumulation: the column sums and products of d loss / d features nearly cancel, so rounding its entries to
+    #  bf16, which the device must do to feed them to an MFMA, moves fc.2.bias by 1e-1 and fc.2.weight by 3.5e-2 against f32
+    #  operands - measured; with the same rounding on both sides what is left is summation order)
+    r16 = lambda t: t.to(torch.bfloat16).to(torch.float32)      # noqa: E731
     hpa = {k: v.clone().requires_grad_(True) for k, v in head_p.items()}
     pin = pooled_in.clone().requires_grad_(True)
-    feats_a, _ = head(pin, hpa, gate)
+    pre_a = F.linear(r16(pin), r16(hpa["0.weight"]), hpa["0.bias"])
+    feats_a = F.linear(r16(pre_a * gate), r16(hpa["2.weight"]), hpa["2.bias"])
     rep["S2 features"] = G.rel_err(feats_in, feats_a.detach())
-    feats_a.backward(dfeats_dev)
+    feats_a.backward(r16(dfeats_dev))
     want.update({"fc." + k: v.grad.clone() for k, v in hpa.items()})
     rep["S4 d pooled"] = G.rel_err(dpooled_dev, pin.grad)
     # S3: the oracle loss at the device's features

@@ -278,7 +278,9 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const GemmGroup g, const 
     stage_group(I0{}, buf1); stage_group(I1{}, buf1);
     wait_vmcnt<WP>();
     asm volatile("s_barrier" ::: "memory");
+#ifndef BVC_G8_NO_STAGGER
     if (wm == 1) asm volatile("s_barrier" ::: "memory");     // the stagger: wave row 1 runs one barrier behind wave row 0
+#endif
 
     Unit cu;
     decode_unit<BM, BN>(g, uid, cu);
@@ -308,6 +310,9 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const GemmGroup g, const 
                 auto phase = [&](auto q_) {
                     constexpr int q = decltype(q_)::value;
                     __builtin_amdgcn_sched_barrier(0);
+#ifdef BVC_G8_DMA_FIRST      // measured alternative (profiles/r03_f_gemm8_loop_variants.txt): the phase's LDS-DMA pieces ahead of its fragment reads
+                    if constexpr (!LATE) { stage_phase(q_, I0{}, cur, oth); stage_phase(q_, I1{}, cur, oth); }
+#endif
                     uint32_t sw = tr_swz;
                     if constexpr (BT && q == 0) asm volatile("" : "+v"(sw));
                     if constexpr (q == 0) {
@@ -323,7 +328,9 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const GemmGroup g, const 
                     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
                         for (int ii = 0; ii < 2; ++ii) af[ks][ii] = read_frag<256, false>(la, wm * WMR + 16 * (2 * q + ii), ks, lane);
+#ifndef BVC_G8_DMA_FIRST
                     if constexpr (!LATE) { stage_phase(q_, I0{}, cur, oth); stage_phase(q_, I1{}, cur, oth); }
+#endif
                     if constexpr (q == 1) {
                         if (after_epi == 0) wait_vmcnt<W1>();
                         else if (after_epi == NSIDE) wait_vmcnt<W1 + NSIDE>();
@@ -727,7 +734,9 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const GemmGroup g, const 
     }
     // drain the out-of-range tail of the stream, then pay back the stagger barrier
     wait_vmcnt<0>();
+#ifndef BVC_G8_NO_STAGGER
     if (wm == 0) asm volatile("s_barrier" ::: "memory");
+#endif
 }
 
 // ------------------------------------------------------------------ host side

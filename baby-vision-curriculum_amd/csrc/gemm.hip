@@ -503,7 +503,15 @@ static int pick_panel(const GemmProblem& p, int cfg, GemmLayout layout) {
     return cost(G) < cost(tiles_n) ? G : tiles_n;
 }
 
-int gemm_num_tiles(const GemmProblem& p, int tile_cfg) { return tiles_for(p, gemm_pick_tile(&p, 1, tile_cfg)); }
+static int pick_gemm8(const GemmProblem* probs, int nprob, GemmLayout layout);
+// (loss partials are written per tile of the kernel that launch_gemm picks for an NT problem: the same selection, gemm8 included)
+int gemm_num_tiles(const GemmProblem& p, int tile_cfg) {
+    if (tile_cfg < 0) {
+        const int g8 = pick_gemm8(&p, 1, GEMM_NT);
+        if (g8 > 0) tile_cfg = g8;
+    }
+    return tiles_for(p, gemm_pick_tile(&p, 1, tile_cfg));
+}
 
 template <int BM, int BN, bool AT, bool BT, int NS, int LB = 2, bool EARLY = true>
 static int launch_one(const GemmGroup& g, int nblocks, hipStream_t stream) {
@@ -580,7 +588,9 @@ static int pick_gemm8(const GemmProblem* probs, int nprob, GemmLayout layout) {
     //  vector instructions nothing hid on this kernel; decoder dX-fc2 at 256 clips 769 vs 878 us - profiles/r02_i_gelu_grad_saved.txt)
     const bool gated = p.epi == EPI_DGELU || p.epi == EPI_DRELU;
     const bool bf = p.epi == EPI_BF16 || p.epi == EPI_GELU || p.epi == EPI_RELU;
-    const bool resid = (p.epi == EPI_RESID || p.epi == EPI_POS || p.epi == EPI_F32) && layout == GEMM_NT;    // f32 out (+ f32 side input)
+    // f32 out (+ f32 side input); the head + MSE product (f32 labels in, bf16 difference out, per-tile loss partials) rides the same
+    // class since round 3: 868 vs 1120 us at 256 clips, 256 vs 303 at 64 (tools/debug/head_loss_ab.py)
+    const bool resid = (p.epi == EPI_RESID || p.epi == EPI_POS || p.epi == EPI_F32 || p.epi == EPI_LOSS) && layout == GEMM_NT;
     if (!bf && !resid && !gated) return -1;
     const int tm = (p.M + 255) / 256, tn256 = (p.N + 255) / 256, tn128 = (p.N + 127) / 128;
     // the register-epilogue class keeps the tile-padded bias vector in 32 KiB of LDS (launch_gemm8 refuses wider outputs)
@@ -595,7 +605,7 @@ static int pick_gemm8(const GemmProblem* probs, int nprob, GemmLayout layout) {
     //  -10 / -21 / -17 %, a loss below 448 tiles - profiles/r02_g_gemm8_resid_ab.txt)
     if (full256 && fits256 && tm * tn256 >= 448) return 10;
     if (gated) return -1;                   // 256 x 128 tiles lose on them at every size measured
-    if (fits128 && (bf ? layout == GEMM_NN : p.N <= 384) && p.K >= 1024 && tm * tn128 >= (resid ? 1024 : 224)) return 11;
+    if (p.epi != EPI_LOSS && fits128 && (bf ? layout == GEMM_NN : p.N <= 384) && p.K >= 1024 && tm * tn128 >= (resid ? 1024 : 224)) return 11;
     return -1;
 }
 

@@ -20,9 +20,10 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
                                                      const float* __restrict__ beta, bf16_t* __restrict__ y, float* __restrict__ y32,
                                                      float* __restrict__ mean, float* __restrict__ rstd, int M, int D, float eps) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int m = blockIdx.x * 4 + wave;
-    if (m >= M) return;
     const int nch = D >> 2;
+    // grid-stride over rows (the launch is capped at a few workgroups per CU): 100352 four-row workgroups per decoder LayerNorm
+    // at 256 clips cost more in workgroup turnover than the rows take to stream
+    for (int m = blockIdx.x * 4 + wave; m < M; m += gridDim.x * 4) {
     const f32x4* xr = reinterpret_cast<const f32x4*>(x + (size_t)map_row(m, rm) * D);
     f32x4 v[kMaxChunks];
     float s = 0.f;
@@ -55,6 +56,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
             if (yf) yf[c] = o;
         }
     }
+    }
 }
 
 // ============================================================================ LayerNorm backward
@@ -82,8 +84,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
         db[i] = f32x4{0, 0, 0, 0};
     }
     const float invD = 1.f / D;
+    // grid-stride over row groups of RPB rows: the launch is capped at a few workgroups per CU, so the column partials below are
+    // written once per RESIDENT workgroup (2048 x 2 D floats) instead of once per RPB rows (25088 x 2 D at the decoder's 256-clip
+    // size: 77 MB per LayerNorm backward, and a reduction kernel to match)
+    const int ngroups = (M + RPB - 1) / RPB;
+    for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x)
     for (int it = 0; it < RPB / 4; ++it) {
-        const int m = blockIdx.x * RPB + it * 4 + wave;
+        const int m = grp * RPB + it * 4 + wave;
         if (m >= M) break;
         const size_t xrow = (size_t)map_row(m, rm) * D;
         const f32x4* xr = reinterpret_cast<const f32x4*>(x + xrow);
@@ -717,10 +724,12 @@ __global__ void nonfinite_check_kernel(const float* __restrict__ x, size_t n, fl
 // ============================================================================ launchers
 static inline unsigned blocks_for(size_t items, int per = 256) { return (unsigned)((items + per - 1) / per); }
 
+constexpr int kLnFwdMaxBlocks = 4096;      // 16 per CU (the kernel holds its row in registers: 8 resident workgroups per CU and a second round)
+
 int launch_ln_fwd(const float* x, RowMap rm, const float* gamma, const float* beta, bf16_t* y, float* mean, float* rstd,
                   int M, int D, float eps, hipStream_t s, float* y32) {
     BVC_REQUIRE(D % 4 == 0 && D <= kMaxChunks * 256, "ln_fwd: D=%d unsupported", D);
-    hipLaunchKernelGGL(ln_fwd_kernel, dim3((M + 3) / 4), dim3(256), 0, s, x, rm, gamma, beta, y, y32, mean, rstd, M, D, eps);
+    hipLaunchKernelGGL(ln_fwd_kernel, dim3(std::min((M + 3) / 4, kLnFwdMaxBlocks)), dim3(256), 0, s, x, rm, gamma, beta, y, y32, mean, rstd, M, D, eps);
     BVC_CHECK_HIP(hipGetLastError());
     return BVC_OK;
 }
@@ -728,6 +737,7 @@ int launch_ln_fwd(const float* x, RowMap rm, const float* gamma, const float* be
 // 64 rows per workgroup for M >= 65536 was measured slower (B=64 decoder: 1276 vs 1157 us per step for the LN backward, which
 // outweighs the 70 us saved in the partial reduction), so the third tier stays unused.
 static inline int ln_bwd_rows_per_block(int M) { return M >= 16384 ? 16 : 4; }
+constexpr int kLnBwdMaxBlocks = 2048;      // 8 per CU: every CU keeps its ~7 resident workgroups (register-limited) busy to the end
 
 size_t ln_bwd_workspace_floats(int M, int D) {
     const int rpb = ln_bwd_rows_per_block(M);
@@ -751,7 +761,7 @@ int launch_ln_bwd(const bf16_t* dy, const float* x, RowMap rm, const float* mean
     // rows per workgroup: enough workgroups to keep >= 16 waves per CU streaming (the kernel is HBM-bound and
     // each wave walks its rows serially), few enough that the per-column atomics stay negligible
     const int rpb = ln_bwd_rows_per_block(M);
-    const int nblk = (M + rpb - 1) / rpb;
+    const int nblk = std::min((M + rpb - 1) / rpb, kLnBwdMaxBlocks);
     const size_t lds = (size_t)8 * D * sizeof(float);
     if (rpb == 64)
         hipLaunchKernelGGL(ln_bwd_kernel<64>, dim3(nblk), dim3(256), lds, s, dy, x, rm, mean, rstd, gamma, dres, accumulate, dres_bf, part, M, D);

@@ -69,6 +69,11 @@ int alloc_stack(Arena& a, Stack& s, int D, int I, int H, int nlayers, float eps,
     BVC_REQUIRE(D % H == 0 && s.hd <= 64 && s.hd % 8 == 0, "stack: head_dim %d unsupported (multiples of 8 up to 64)", s.hd);
     s.Da = H * s.hdp;
     const size_t Da = s.Da;
+    // operand extents travel as 32-bit byte counts (bvc_gemm_desc.a_bytes / b_bytes, buffer descriptors): the widest bf16
+    // activation of a layer has to stay below 4 GiB (VideoMAE-base decoder: ~890 clips per GPU; from 2 GiB on - 445 clips - the
+    // 256-row persistent kernel, which marks dropped loads with offset bit 31, hands the product to the 128 x 128 kernels)
+    BVC_REQUIRE(M * std::max<size_t>(3 * Da, (size_t)I) * 2 < 0xFFFFFFF0ull,
+                "stack: %zu tokens x %zu columns of bf16 exceed the 4 GiB operand extent; use a smaller per-GPU batch", M, std::max<size_t>(3 * Da, (size_t)I));
     if (s.hdp != s.hd) {
         TRY(a.alloc(&s.wqkv_pad, 3 * Da * D));
         TRY(a.alloc(&s.wo_pad, (size_t)D * Da));

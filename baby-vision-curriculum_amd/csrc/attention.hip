@@ -404,326 +404,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
     }
 }
 
-// ============================================================================ one wave = NB x 32 rows (experiment, round 2)
-// NOT on the product path: compiled only into an experiments build (-DBVC_EXPERIMENTS) and selected there by BVC_ATTN_DQ_W=1, for
-// the A/B recorded in profiles/r02_h_attention_single_wave.txt.  Result: 3-4 % faster than the 32-row dQ kernel at the decoder
-// shape, equal at N = 160, 15 % slower at head_dim 32 - not worth its inline-asm hazard contract, so the 32-row kernels stay.
+// (the single-wave 96-query dQ experiment of round 2 - 3-4 % at the decoder shape, not adopted, profiles/r02_h_attention_single_wave.txt -
+//  lives in experiments/attention_dq_wave96.inc and is compiled only into a -DBVC_EXPERIMENTS build)
 #ifdef BVC_EXPERIMENTS
-// The kernels above give every wave 32 rows and read each K / V (or Q / dO) fragment from LDS for ONE 32 x 32 score block:
-// 16 LDS instructions (12 KiB) per 12 MFMAs in dQ (counters: profiles/r02_h_attention_single_wave.txt).
-// The kernel below gives ONE wave NB = 3 blocks of 32 rows (96 queries) and the whole 512-register file
-// (one wave per SIMD, four single-wave workgroups per CU): every fragment read from LDS feeds NB MFMAs, the NB blocks are
-// independent dependency chains (one block's softmax arithmetic runs beside another block's MFMAs), and with one wave per
-// workgroup there is no barrier at all: the K / V (Q / dO) stream is a private 4-stage ring of 32-row tiles filled by LDS-DMA
-// three tiles ahead behind a counted vmcnt.
-constexpr int kRing = 4;          // LDS stages of one 32-row tile pair; prefetch distance kRing - 1
-
-template <int N>
-__device__ __forceinline__ void attn_wait_vmcnt() {
-#if defined(BVC_ATTN_ABL) && (BVC_ATTN_ABL & 1)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#else
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+#include "experiments/attention_dq_wave96.inc"
 #endif
-}
-
-// per-lane source byte offsets of the HD/16 pieces (1 KiB of LDS each) of a 32 x HD tile image, for tile row 0
-template <int HD>
-struct TileSrc { uint32_t v[HD / 16]; };
-template <int HD>
-__device__ __forceinline__ TileSrc<HD> make_tile_src(int lane, int ld, int col0) {
-    constexpr int CPR = HD / 8, RPP = 64 / CPR;   // 16-B chunks per row, rows per piece
-    TileSrc<HD> t;
-#pragma unroll
-    for (int j = 0; j < HD / 16; ++j) {
-        const int r = RPP * j + lane / CPR;
-        const int c = (lane % CPR) ^ swz_dual<HD>(r);
-        t.v[j] = (uint32_t)((r * ld + col0 + c * 8) * 2);
-    }
-    return t;
-}
-// rows [row, row + 32) of the source (row_bytes = row * ld * 2, wave-uniform) -> the image at lds_addr; soff = wave-uniform extra bytes
-template <int HD>
-__device__ __forceinline__ void stage32(__amdgpu_buffer_rsrc_t rs, const TileSrc<HD>& src, uint32_t row_bytes, uint32_t soff, uint32_t lds_addr) {
-#pragma unroll
-    for (int j = 0; j < HD / 16; ++j) glds16s(rs, src.v[j] + row_bytes, soff, lds_addr + 1024u * j);
-}
-
-// acc += A B with the accumulator pinned to the AGPR half of the register file (inline asm: the compiler's own MFMA selection is
-// all-VGPR or all-AGPR per function, and these kernels need both: the score accumulators are VALU operands, the 96 registers of
-// dQ^T / dK^T / dV^T are touched by MFMAs only).  hipcc does not know this is an MFMA, so the CALLER keeps the hazard distances:
-// a dependent MFMA on the same accumulator at least two MFMA slots later, operands that no VALU instruction wrote in the last two
-// issue slots, a VALU read of the accumulator only after `mfma_drain()`.
-__device__ __forceinline__ void mfma_acc(f32x16& acc, const bf16x8& a, const bf16x8& b) {
-    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
-}
-// the same with two wait states in front: for an operand a VALU instruction may have written just before (the hazard hipcc covers
-// with an s_nop for its own MFMAs)
-__device__ __forceinline__ void mfma_acc_safe(f32x16& acc, const bf16x8& a, const bf16x8& b) {
-    asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
-}
-__device__ __forceinline__ void mfma_drain() { asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); }
-
-// ---------------------------------------------------------------------------- dQ, one wave = NB x 32 queries
-// One wave per SIMD: nothing but this wave's own instruction order overlaps softmax arithmetic, LDS latency and DMA issue with
-// the MFMAs (left to hipcc, each block's 8 score MFMAs issue back to back and its 64 VALU after them: no faster than the 32-row
-// kernel).  The stream is therefore software-pipelined by hand and pinned with sched_barrier(0).  Per 32-key tile t and query
-// block b: M1(b,t) = 8 score MFMAs (S^T and dP^T chains alternating), V(b,t) = 8 steps of two score elements each (fma, exp, sub,
-// mul, one packed convert: ~40 issue cycles), M2(b,t) = 4 MFMAs of the dQ^T update.  Phase b of tile t issues
-//     M1(b+1, t)  [b = NB-1: M1(0, t+1)]   beside   V(b, t),   then   M2(b-1, t)   [b = 0: none],
-// one MFMA per slot with a V step in two slots of three, and a last short phase issues M2(NB-1, t).  The slots without a V step
-// carry the fragment reads (K^T of tile t in phase 0, the K / V rows of tile t+1 at the end of phase 1, into the registers M1(NB-1, t)
-// has just finished with) and the LDS-DMA of tile t+3.  Every MFMA operand and every V step's scores are at least four slots old.
-// The pipelined loop covers the full tiles; a ragged last tile (N mod 32 keys) runs once through `dq_tile_rag` after it.
-template <int HD, int NB>
-struct DqState {
-    static constexpr int NS = HD / 16, NT = HD / 32;
-    bf16x8 kr[NS], vr[NS];             // K / V row fragments (A operands of S^T, dP^T)
-    bf16x8 kt[2][NT];                  // K^T fragments (A operand of dQ^T), by k-step, head-dim block
-    f32x16 s[NB], dp[NB];
-    union { bf16x8 v; uint32_t u[4]; } d[NB][2];
-};
-
-#define BVC_PIN() __builtin_amdgcn_sched_barrier(0)
-// S = ring stage of tile t (t mod 4)
-template <int HD, int NB, int S, typename Dma>
-__device__ __forceinline__ void dq_tile_r(DqState<HD, NB>& st, const AS3 char* lds, const FragAddr<HD>& fa, const bf16x8 (&qf)[NB][HD / 16],
-                                          const bf16x8 (&dof)[NB][HD / 16], f32x16 (&dq)[NB][HD / 32], float scale_log2,
-                                          const float (&nlse)[NB], const float (&del_q)[NB], Dma&& dma) {
-    constexpr int IMG = 32 * HD * 2, STG = 2 * IMG, KS = 16 * HD * 2, NS = HD / 16, NT = HD / 32;
-    constexpr int KOFF = S * STG, KNXT = ((S + 1) & (kRing - 1)) * STG, VNXT = KNXT + IMG;
-    constexpr int M1N = 2 * NS, M2N = 2 * NT, PCS = 2 * NS;
-    auto m1 = [&](int blk, int i) {     // score MFMA i of block blk
-        const int stp = i >> 1;
-        if ((i & 1) == 0) st.s[blk] = MFMA32(st.kr[stp], qf[blk][stp], stp == 0 ? zero16() : st.s[blk]);
-        else st.dp[blk] = MFMA32(st.vr[stp], dof[blk][stp], stp == 0 ? zero16() : st.dp[blk]);
-    };
-    auto m2 = [&](int blk, int i) {
-        const int ks = i / NT, t = i % NT;
-        mfma_acc(dq[blk][t], st.kt[ks][t], st.d[blk][ks].v);
-        if (NT == 1) mfma_drain();      // head_dim 32: the two updates of a block hit the same accumulator back to back
-    };
-    // elements 2i, 2i+1 of block blk: dS^T (without the 1/sqrt(d) factor, applied at the end) -> one packed word of its fragment
-    auto vstep = [&](int blk, int i) {
-#if defined(BVC_ATTN_ABL) && (BVC_ATTN_ABL & 2)
-        const float a = st.s[blk][2 * i] + st.dp[blk][2 * i], c = st.s[blk][2 * i + 1] + st.dp[blk][2 * i + 1];
-#else
-        const float a = fast_exp2(fmaf(st.s[blk][2 * i], scale_log2, nlse[blk])) * (st.dp[blk][2 * i] - del_q[blk]);
-        const float c = fast_exp2(fmaf(st.s[blk][2 * i + 1], scale_log2, nlse[blk])) * (st.dp[blk][2 * i + 1] - del_q[blk]);
-#endif
-        st.d[blk][i >> 2].u[i & 3] = pack2bf(a, c);
-    };
-    int piece = 0;                      // DMA instructions of tile t+3 issued so far
-#pragma unroll
-    for (int ph = 0; ph < NB; ++ph) {
-        const int slots = M1N + (ph > 0 ? M2N : 0);
-        int vs = 0;
-#pragma unroll
-        for (int i = 0; i < slots; ++i) {
-            if (i < M1N) m1(ph + 1 < NB ? ph + 1 : 0, i);
-            else m2(ph - 1, i - M1N);
-            const bool free_slot = (i % 3 == 2) || i >= M1N;
-            if (!free_slot || slots == M1N) { if (vs < 8) vstep(ph, vs++); }
-            constexpr int KT1 = M1N >= 8 ? 4 : M1N - 1;      // slot of the second K^T k-step
-#if defined(BVC_ATTN_ABL) && (BVC_ATTN_ABL & 4)
-            constexpr bool kReload = false;
-#else
-            constexpr bool kReload = true;
-#endif
-            if (kReload && ph == 0 && (i == 1 || i == KT1)) {          // K^T of this tile (first needed by M2(0, t) in phase 1)
-                const int ks = i == 1 ? 0 : 1;
-#pragma unroll
-                for (int t = 0; t < NT; ++t) st.kt[ks][t] = lds_tr<KOFF>(lds, fa.tr[t][0] + ks * KS, fa.tr[t][1] + ks * KS);
-            }
-            if (kReload && ph == NB - 2 && i >= M1N) {                  // rows of tile t+1: M1(NB-1, t) has issued, M1(0, t+1) opens the next phase
-                const int k = i - M1N;                       // 0 .. M2N-1
-#pragma unroll
-                for (int stp = k * NS / M2N; stp < (k + 1) * NS / M2N; ++stp) st.kr[stp] = lds_rows<KNXT>(lds, fa.rows[stp]);
-#pragma unroll
-                for (int stp = k * NS / M2N; stp < (k + 1) * NS / M2N; ++stp) st.vr[stp] = lds_rows<VNXT>(lds, fa.rows[stp]);
-            }
-            if (ph == NB - 1 && free_slot && piece < PCS) dma(piece++);
-            BVC_PIN();
-        }
-#pragma unroll
-        for (; vs < 8; ++vs) { vstep(ph, vs); BVC_PIN(); }
-    }
-#pragma unroll
-    for (int i = 0; i < M2N; ++i) {
-        m2(NB - 1, i);
-#pragma unroll
-        for (int k = 0; k < 2; ++k) if (piece < PCS) dma(piece++);
-        BVC_PIN();
-    }
-#pragma unroll
-    for (; piece < PCS; ++piece) dma(piece);
-}
-
-// the ragged last tile (keys >= N masked), once per workgroup and not pipelined; `stage` = byte offset of its ring stage
-template <int HD, int NB>
-__device__ __forceinline__ void dq_tile_rag(const AS3 char* lds, uint32_t stage, const FragAddr<HD>& fa, const bf16x8 (&qf)[NB][HD / 16],
-                                         const bf16x8 (&dof)[NB][HD / 16], f32x16 (&dq)[NB][HD / 32], int key0, int N, int h,
-                                         float scale_log2, const float (&nlse)[NB], const float (&del_q)[NB]) {
-    constexpr int IMG = 32 * HD * 2, KS = 16 * HD * 2, NS = HD / 16, NT = HD / 32;
-    bf16x8 kr[NS], vr[NS], kt[2][NT];
-#pragma unroll
-    for (int stp = 0; stp < NS; ++stp) { kr[stp] = lds_rows<0>(lds, fa.rows[stp] + stage); vr[stp] = lds_rows<IMG>(lds, fa.rows[stp] + stage); }
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        kt[0][t] = lds_tr<0>(lds, fa.tr[t][0] + stage, fa.tr[t][1] + stage);
-        kt[1][t] = lds_tr<KS>(lds, fa.tr[t][0] + stage, fa.tr[t][1] + stage);
-    }
-    union { bf16x8 v; uint32_t u[4]; } d[NB][2];
-#pragma unroll
-    for (int blk = 0; blk < NB; ++blk) {
-        f32x16 s = zero16(), dp = zero16();
-#pragma unroll
-        for (int stp = 0; stp < NS; ++stp) {
-            s = MFMA32(kr[stp], qf[blk][stp], s);
-            dp = MFMA32(vr[stp], dof[blk][stp], dp);
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            s[r] = fast_exp2(fmaf(s[r], scale_log2, nlse[blk])) * (dp[r] - del_q[blk]);
-            if (key0 + acc_row(r, h) >= N) s[r] = 0.f;
-        }
-        d[blk][0].v = acc_to_frag(s, 0);
-        d[blk][1].v = acc_to_frag(s, 1);
-    }
-    // block-major inside each (k-step, head-dim block): MFMAs on one accumulator stay NB slots apart
-#pragma unroll
-    for (int i = 0; i < 2 * NT; ++i)
-#pragma unroll
-        for (int blk = 0; blk < NB; ++blk) mfma_acc_safe(dq[blk][i % NT], kt[i / NT][i % NT], d[blk][i / NT].v);
-}
-
-// grid ceil(N / (32 NB)) * B*H single-wave workgroups; lane (i, h) owns query column i of each of the wave's NB blocks
-template <int HD, int NB>
-__global__ __launch_bounds__(64) void attn_bwd_dq_w_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dctx,
-                                                           const bf16_t* __restrict__ ctx, const float* __restrict__ lse,
-                                                           float* __restrict__ delta, bf16_t* __restrict__ dqkv, int N, int H, int D,
-                                                           uint32_t qkv_bytes, float scale, float scale_log2, int remap) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int IMG = 32 * HD * 2, STG = 2 * IMG, NS = HD / 16, NT = HD / 32, PCS = 2 * NS;   // PCS: DMA instructions per tile (K + V)
-    const AS3 char* lds = (const AS3 char*)smem;
-    const uint32_t lds0 = (uint32_t)(size_t)((AS3 char*)smem);
-    const int lane = threadIdx.x;
-    int tile_, bh;
-    attn_block((N + 32 * NB - 1) / (32 * NB), remap, tile_, bh);
-    const int b = bh / H, head = bh % H;
-    const int ld = 3 * D;
-    const int h = lane >> 5;
-    const __amdgpu_buffer_rsrc_t rs = make_rsrc(qkv, qkv_bytes);
-    const FragAddr<HD> fa = make_frag_addr<HD>(lane);
-
-    bf16x8 qf[NB][NS], dof[NB][NS];
-    float del_q[NB], nlse[NB];
-#pragma unroll
-    for (int blk = 0; blk < NB; ++blk) {
-        const int qi = tile_ * 32 * NB + 32 * blk + (lane & 31);
-        const int qc = min(qi, N - 1);
-        const bf16_t* qrow = qkv + (size_t)(b * N + qc) * ld + head * HD + 8 * h;
-        const bf16_t* drow = dctx + (size_t)(b * N + qc) * D + head * HD + 8 * h;
-        const bf16_t* orow_in = ctx + (size_t)(b * N + qc) * D + head * HD + 8 * h;
-        float dl = 0.f;
-#pragma unroll
-        for (int stp = 0; stp < NS; ++stp) {
-            qf[blk][stp] = load8(qrow + 16 * stp);
-            dof[blk][stp] = load8(drow + 16 * stp);
-            // delta = rowsum(dO * O) of this query: the two half-waves hold disjoint halves of the row
-            const bf16x8 of = load8(orow_in + 16 * stp);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) dl += bf2f((bf16_t)dof[blk][stp][j]) * bf2f((bf16_t)of[j]);
-        }
-        dl += __shfl_xor(dl, 32, 64);
-        if (h == 0 && qi < N) delta[(size_t)bh * N + qi] = -dl;     // negated, as attn_bwd_dq_kernel stores it
-        del_q[blk] = dl;
-        nlse[blk] = -lse[(size_t)bh * N + qc];
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the loads and the delta stores above leave the counter before the stream starts
-#pragma unroll
-    for (int blk = 0; blk < NB; ++blk) {
-#pragma unroll
-        for (int stq = 0; stq < NS; ++stq) { settle(qf[blk][stq]); settle(dof[blk][stq]); }
-        settle(nlse[blk]); settle(del_q[blk]);
-    }
-    f32x16 dq[NB][NT];
-#pragma unroll
-    for (int blk = 0; blk < NB; ++blk)
-#pragma unroll
-        for (int t = 0; t < NT; ++t) { dq[blk][t] = zero16(); asm volatile("" : "+a"(dq[blk][t])); }   // zeroed HERE, not lazily in front of the first
-    mfma_drain();                                                                                       // update (AGPR write -> MFMA read is a hazard hipcc cannot see)
-
-    const int nt = (N + 31) >> 5, nfull = N >> 5;
-    const TileSrc<HD> ksrc = make_tile_src<HD>(lane, ld, D + head * HD);
-    const uint32_t tile_bytes = (uint32_t)(32 * ld * 2), row0_bytes = (uint32_t)((size_t)b * N * ld * 2), vshift = (uint32_t)(2 * D);
-    // DMA instruction j (0 .. PCS-1) of tile t: the K pieces, then the V pieces (same rows, + 2 D bytes).  Tiles past the clip are
-    // issued too (their rows are the next clip's, or out of range -> zeros): the counted waits then need no tail cases.
-    auto dma_piece = [&](int t, int j) {
-#if defined(BVC_ATTN_ABL) && (BVC_ATTN_ABL & 1)
-        if (t >= kRing - 1) return;
-#endif
-        const uint32_t dst = lds0 + (uint32_t)(t & (kRing - 1)) * STG + (j >= NS ? IMG : 0) + 1024u * (j % NS);
-        glds16s(rs, ksrc.v[j % NS] + row0_bytes + (uint32_t)t * tile_bytes, j >= NS ? vshift : 0u, dst);
-    };
-    DqState<HD, NB> st;
-#pragma unroll
-    for (int t = 0; t < kRing - 1; ++t)
-#pragma unroll
-        for (int j = 0; j < PCS; ++j) dma_piece(t, j);
-    if (nfull > 0) {
-        attn_wait_vmcnt<2 * PCS>();        // tile 0 has landed
-#pragma unroll
-        for (int stp = 0; stp < NS; ++stp) { st.kr[stp] = lds_rows<0>(lds, fa.rows[stp]); st.vr[stp] = lds_rows<IMG>(lds, fa.rows[stp]); }
-#pragma unroll
-        for (int i = 0; i < 2 * NS; ++i) {
-            const int stp = i >> 1;
-            if ((i & 1) == 0) st.s[0] = MFMA32(st.kr[stp], qf[0][stp], stp == 0 ? zero16() : st.s[0]);
-            else st.dp[0] = MFMA32(st.vr[stp], dof[0][stp], stp == 0 ? zero16() : st.dp[0]);
-        }
-#if defined(BVC_ATTN_ABL) && (BVC_ATTN_ABL & 4)
-#pragma unroll
-        for (int tt = 0; tt < NT; ++tt) { st.kt[0][tt] = lds_tr<0>(lds, fa.tr[tt][0], fa.tr[tt][1]); st.kt[1][tt] = lds_tr<16 * HD * 2>(lds, fa.tr[tt][0], fa.tr[tt][1]); }
-#endif
-        // top of tile t: tile t+1 must have landed (its fragments are read during tile t); outstanding: tile t+2 only
-        int t = 0;
-        attn_wait_vmcnt<PCS>();
-        dq_tile_r<HD, NB, 0>(st, lds, fa, qf, dof, dq, scale_log2, nlse, del_q, [&](int j) { dma_piece(t + 3, j); });
-        for (t = 1; t < nfull;) {
-            attn_wait_vmcnt<PCS>(); dq_tile_r<HD, NB, 1>(st, lds, fa, qf, dof, dq, scale_log2, nlse, del_q, [&](int j) { dma_piece(t + 3, j); });
-            if (++t >= nfull) break;
-            attn_wait_vmcnt<PCS>(); dq_tile_r<HD, NB, 2>(st, lds, fa, qf, dof, dq, scale_log2, nlse, del_q, [&](int j) { dma_piece(t + 3, j); });
-            if (++t >= nfull) break;
-            attn_wait_vmcnt<PCS>(); dq_tile_r<HD, NB, 3>(st, lds, fa, qf, dof, dq, scale_log2, nlse, del_q, [&](int j) { dma_piece(t + 3, j); });
-            if (++t >= nfull) break;
-            attn_wait_vmcnt<PCS>(); dq_tile_r<HD, NB, 0>(st, lds, fa, qf, dof, dq, scale_log2, nlse, del_q, [&](int j) { dma_piece(t + 3, j); });
-            ++t;
-        }
-    }
-    mfma_drain();                                       // before anything hipcc may place here touches the accumulators
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no LDS-DMA may be in flight when the workgroup's LDS is released
-    if (nt > nfull) dq_tile_rag<HD, NB>(lds, (uint32_t)(nfull & (kRing - 1)) * STG, fa, qf, dof, dq, 32 * nfull, N, h, scale_log2, nlse, del_q);
-    mfma_drain();                                       // the accumulators are read by VALU next
-
-#pragma unroll
-    for (int blk = 0; blk < NB; ++blk) {
-        const int qi = tile_ * 32 * NB + 32 * blk + (lane & 31);
-        if (qi < N) {
-            bf16_t* orow = dqkv + (size_t)(b * N + qi) * ld + head * HD;
-#pragma unroll
-            for (int t2 = 0; t2 < NT; ++t2)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int d = 32 * t2 + 8 * g + 4 * h;
-                    uint2 a = {pack2bf(dq[blk][t2][4 * g] * scale, dq[blk][t2][4 * g + 1] * scale),
-                               pack2bf(dq[blk][t2][4 * g + 2] * scale, dq[blk][t2][4 * g + 3] * scale)};
-                    *reinterpret_cast<uint2*>(orow + d) = a;
-                }
-        }
-    }
-}
-#undef BVC_PIN
-#endif  // BVC_EXPERIMENTS
 
 // ============================================================================ dK, dV
 // LDS stage = Q image | dO image | lse 256 B | -delta 256 B

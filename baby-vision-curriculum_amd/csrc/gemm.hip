@@ -559,7 +559,7 @@ static int launch_stages(const GemmGroup& g, GemmLayout layout, int stages, int 
 // slower (they cost the second resident workgroup per CU), so `stages` is accepted for API stability and ignored.
 int gemm_pick_stages(int, GemmLayout, int, int stages) { return (stages == 3 || stages == 4) ? stages : 2; }
 
-int launch_gemm_big_nt(const GemmProblem& p, int cfg, hipStream_t stream);   // gemm_big.hip (experiments: tile configs 3-5)
+int launch_gemm_big_nt(const GemmProblem& p, int cfg, hipStream_t stream);   // experiments/gemm_big.hip (tile configs 3-5, experiments build only)
 // gemm_persist.hip; returns 1 when the problem is not eligible.  defer: 0 = stores in the epilogue, 1 = deferred where possible,
 // 2 = deferred or not at all (tile config 9, tests)
 int launch_gemm_persist(const GemmGroup& g, GemmLayout layout, int cfg, hipStream_t stream, int defer);
@@ -622,7 +622,7 @@ int launch_gemm(const GemmProblem* probs, int nprob, GemmLayout layout, int tile
         BVC_REQUIRE(nprob == 1 && layout == GEMM_NT, "launch_gemm: tile configs 3-5 (32-deep K steps) are NT, one problem");
         return launch_gemm_big_nt(probs[0], tile_cfg, stream);
 #else
-        BVC_REQUIRE(false, "launch_gemm: tile configs 3-5 / 8 exist only in a -DBVC_EXPERIMENTS build (csrc/gemm_big.hip)");
+        BVC_REQUIRE(false, "launch_gemm: tile configs 3-5 / 8 exist only in a -DBVC_EXPERIMENTS build (csrc/experiments/gemm_big.hip)");
 #endif
     }
     const int cfg = gemm_pick_tile(probs, nprob, tile_cfg);

@@ -10,7 +10,7 @@ namespace bvc {
 #endif
 
 // Experiment hooks (BVC_GEMM_DEBUG bits inside the kernels, per-launch environment switches, the 32-deep-K kernels of
-// gemm_big.hip behind tile configs 3-5 / 8) exist only in a -DBVC_EXPERIMENTS build (BVC_EXTRA_HIPCC_FLAGS=-DBVC_EXPERIMENTS,
+// experiments/gemm_big.hip behind tile configs 3-5 / 8) exist only in a -DBVC_EXPERIMENTS build (BVC_EXTRA_HIPCC_FLAGS=-DBVC_EXPERIMENTS,
 // used by tools/gemm_dbg.py, tools/gemm_ksweep.py and the same-process A/Bs of tools/microbench.py); the product library
 // compiles them out.
 #ifdef BVC_EXPERIMENTS

@@ -13,42 +13,57 @@ __device__ __forceinline__ int map_row(int m, RowMap rm) {
     return rm.rin > 0 ? (m / rm.rin) * rm.rout + rm.roff + (m % rm.rin) : m;
 }
 
+// sum over the LPR lanes that share a row (64: the wave; 32: each half-wave holds its own row - xor distances < 32 stay inside a half)
+template <int LPR>
+__device__ __forceinline__ float row_sum(float v) {
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
 // ============================================================================ LayerNorm forward
-// one wave per row; y = (x - mean) * rstd * gamma + beta in bf16; saves mean / rstd (biased variance,
+// LPR lanes per row: 64 (one wave per row) or 32 (two rows per wave: widths up to 512 that are multiples of 128 - the decoder's and
+// the predictor's 384 - would leave half of the wave idle in the second of their 1.5 float4 chunks per lane); y = (x - mean) * rstd * gamma + beta in bf16; saves mean / rstd (biased variance,
 // torch.nn.LayerNorm semantics, HF:336-337)
+template <int LPR>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, RowMap rm, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, bf16_t* __restrict__ y, float* __restrict__ y32,
                                                      float* __restrict__ mean, float* __restrict__ rstd, int M, int D, float eps) {
+    constexpr int RPW = 64 / LPR, RPBK = 4 * RPW;        // rows per wave, rows per workgroup and pass
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane % LPR, rsel = lane / LPR;
     const int nch = D >> 2;
     // grid-stride over rows (the launch is capped at a few workgroups per CU): 100352 four-row workgroups per decoder LayerNorm
     // at 256 clips cost more in workgroup turnover than the rows take to stream
-    for (int m = blockIdx.x * 4 + wave; m < M; m += gridDim.x * 4) {
-    const f32x4* xr = reinterpret_cast<const f32x4*>(x + (size_t)map_row(m, rm) * D);
+    for (int m0 = blockIdx.x * RPBK + wave * RPW; m0 < M; m0 += gridDim.x * RPBK) {
+    const int m = m0 + rsel;
+    const bool live = m < M;                             // (a half-wave past the last row idles; its shuffles stay in its own half)
+    const f32x4* xr = reinterpret_cast<const f32x4*>(x + (size_t)map_row(live ? m : M - 1, rm) * D);
     f32x4 v[kMaxChunks];
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < kMaxChunks; ++i) {
-        const int c = lane + 64 * i;
+        const int c = sub + LPR * i;
         if (c < nch) { v[i] = xr[c]; s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]); }
     }
-    const float mu = wave_sum(s) / D;
+    const float mu = row_sum<LPR>(s) / D;
     float q = 0.f;
 #pragma unroll
     for (int i = 0; i < kMaxChunks; ++i) {
-        const int c = lane + 64 * i;
+        const int c = sub + LPR * i;
         if (c < nch) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mu; q += d * d; }
         }
     }
-    const float rs = rsqrtf(wave_sum(q) / D + eps);
-    if (lane == 0 && mean) { mean[m] = mu; rstd[m] = rs; }
+    const float rs = rsqrtf(row_sum<LPR>(q) / D + eps);
+    if (!live) continue;
+    if (sub == 0 && mean) { mean[m] = mu; rstd[m] = rs; }
     uint2* yr = y ? reinterpret_cast<uint2*>(y + (size_t)m * D) : nullptr;
     f32x4* yf = y32 ? reinterpret_cast<f32x4*>(y32 + (size_t)m * D) : nullptr;
 #pragma unroll
     for (int i = 0; i < kMaxChunks; ++i) {
-        const int c = lane + 64 * i;
+        const int c = sub + LPR * i;
         if (c < nch) {
             f32x4 o = (v[i] - mu) * rs;
             if (gamma) o = o * reinterpret_cast<const f32x4*>(gamma)[c] + reinterpret_cast<const f32x4*>(beta)[c];
@@ -64,21 +79,23 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 // per-workgroup partials of dgamma = sum_rows dy * xhat and dbeta = sum_rows dy go to part[block][2][D]
 // (every workgroup hammering the same D addresses with atomics serialises: measured 2x on the kernel);
 // ln_param_reduce_kernel folds them into the gradients
-template <int RPB>
+template <int RPB, int LPR>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ dy, const float* __restrict__ x, RowMap rm,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ gamma, float* __restrict__ dres,
                                                      int accumulate, bf16_t* __restrict__ dres_bf, float* __restrict__ part,
                                                      int M, int D) {
-    // per-wave column partials, [wave][dgamma | dbeta][D]: sized by D at launch (a static 32 KiB array capped the kernel at
-    // 5 workgroups per CU; at D = 384 this is 12 KiB and the register budget decides: 7)
+    // per-wave (per half-wave for LPR = 32) column partials, [4 RPW][dgamma | dbeta][D]: sized by D at launch (a static 32 KiB array
+    // capped the kernel at 5 workgroups per CU; at D = 384 this is 24 KiB and the register budget decides: 6-7)
     extern __shared__ __attribute__((aligned(16))) float red[];
+    constexpr int RPW = 64 / LPR;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane % LPR, rsel = lane / LPR;
     const int nch = D >> 2;
     f32x4 gam[kMaxChunks], dg[kMaxChunks], db[kMaxChunks];
 #pragma unroll
     for (int i = 0; i < kMaxChunks; ++i) {
-        const int c = lane + 64 * i;
+        const int c = sub + LPR * i;
         gam[i] = c < nch ? reinterpret_cast<const f32x4*>(gamma)[c] : f32x4{0, 0, 0, 0};
         dg[i] = f32x4{0, 0, 0, 0};
         db[i] = f32x4{0, 0, 0, 0};
@@ -89,22 +106,26 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
     // size: 77 MB per LayerNorm backward, and a reduction kernel to match)
     const int ngroups = (M + RPB - 1) / RPB;
     for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x)
-    for (int it = 0; it < RPB / 4; ++it) {
-        const int m = grp * RPB + it * 4 + wave;
-        if (m >= M) break;
-        const size_t xrow = (size_t)map_row(m, rm) * D;
+    for (int it = 0; it < RPB / (4 * RPW); ++it) {
+        const int mw = grp * RPB + (it * 4 + wave) * RPW;     // first row of this wave
+        if (mw >= M) break;
+        const int m = mw + rsel;
+        const bool live = m < M;
+        const int mc = live ? m : M - 1;
+        const size_t xrow = (size_t)map_row(mc, rm) * D;
         const f32x4* xr = reinterpret_cast<const f32x4*>(x + xrow);
-        const uint2* dyr = reinterpret_cast<const uint2*>(dy + (size_t)m * D);
-        const float mu = mean[m], rs = rstd[m];
+        const uint2* dyr = reinterpret_cast<const uint2*>(dy + (size_t)mc * D);
+        const float mu = mean[mc], rs = rstd[mc];
         f32x4 xh[kMaxChunks], g[kMaxChunks];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int i = 0; i < kMaxChunks; ++i) {
-            const int c = lane + 64 * i;
+            const int c = sub + LPR * i;
             if (c < nch) {
                 const uint2 d = dyr[c];
-                const f32x4 dyv = {__uint_as_float(d.x << 16), __uint_as_float(d.x & 0xffff0000u),
-                                   __uint_as_float(d.y << 16), __uint_as_float(d.y & 0xffff0000u)};
+                f32x4 dyv = {__uint_as_float(d.x << 16), __uint_as_float(d.x & 0xffff0000u),
+                             __uint_as_float(d.y << 16), __uint_as_float(d.y & 0xffff0000u)};
+                if (!live) dyv = f32x4{0, 0, 0, 0};      // a half-wave past the last row adds nothing to the column sums
                 xh[i] = (xr[c] - mu) * rs;
                 g[i] = dyv * gam[i];
                 dg[i] += dyv * xh[i];
@@ -113,13 +134,14 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
                 for (int e = 0; e < 4; ++e) { s1 += g[i][e]; s2 += g[i][e] * xh[i][e]; }
             }
         }
-        s1 = wave_sum(s1) * invD;
-        s2 = wave_sum(s2) * invD;
+        s1 = row_sum<LPR>(s1) * invD;
+        s2 = row_sum<LPR>(s2) * invD;
+        if (!live) continue;
         f32x4* dr = reinterpret_cast<f32x4*>(dres + xrow);
         uint2* db16 = dres_bf ? reinterpret_cast<uint2*>(dres_bf + xrow) : nullptr;
 #pragma unroll
         for (int i = 0; i < kMaxChunks; ++i) {
-            const int c = lane + 64 * i;
+            const int c = sub + LPR * i;
             if (c < nch) {
                 f32x4 dx = (g[i] - s1 - xh[i] * s2) * rs;
                 if (accumulate) dx += dr[c];
@@ -128,20 +150,24 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
             }
         }
     }
-    // cross-wave reduction of the column partials, then one atomic per column per workgroup
+    // cross-wave reduction of the column partials (4 RPW of them), then one partial row per workgroup
+    const int slot = wave * RPW + rsel;
 #pragma unroll
     for (int i = 0; i < kMaxChunks; ++i) {
-        const int c = lane + 64 * i;
+        const int c = sub + LPR * i;
         if (c < nch) {
-            *reinterpret_cast<f32x4*>(red + (wave * 2 + 0) * D + c * 4) = dg[i];
-            *reinterpret_cast<f32x4*>(red + (wave * 2 + 1) * D + c * 4) = db[i];
+            *reinterpret_cast<f32x4*>(red + (slot * 2 + 0) * D + c * 4) = dg[i];
+            *reinterpret_cast<f32x4*>(red + (slot * 2 + 1) * D + c * 4) = db[i];
         }
     }
     __syncthreads();
     float* pg = part + (size_t)blockIdx.x * 2 * D;
     for (int col = threadIdx.x; col < D; col += 256) {
-        pg[col] = (red[0 * D + col] + red[2 * D + col]) + (red[4 * D + col] + red[6 * D + col]);
-        pg[D + col] = (red[1 * D + col] + red[3 * D + col]) + (red[5 * D + col] + red[7 * D + col]);
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4 * RPW; ++w) { a += red[(2 * w) * D + col]; b += red[(2 * w + 1) * D + col]; }
+        pg[col] = a;
+        pg[D + col] = b;
     }
 }
 
@@ -724,12 +750,27 @@ __global__ void nonfinite_check_kernel(const float* __restrict__ x, size_t n, fl
 // ============================================================================ launchers
 static inline unsigned blocks_for(size_t items, int per = 256) { return (unsigned)((items + per - 1) / per); }
 
+// two rows per wave (32 lanes each) when a row is at most 512 wide and a whole number of float4 per lane: 384 = 3 per lane
+static inline bool ln_half_wave_rows(int D) { return D <= 512 && D % 128 == 0; }
+// grid of a grid-stride row kernel: at most `cap` workgroups, and every workgroup the same number of row groups (2560 groups on
+// 2048 workgroups would give a quarter of them twice the work of the rest)
+static inline int balanced_grid(int ngroups, int cap) {
+    if (ngroups <= cap) return ngroups > 0 ? ngroups : 1;
+    // a few groups per workgroup: keep every CU's resident slots full rather than even (encoder LayerNorm backward at 256 clips,
+    // 2560 groups: 2048 workgroups 99-105 us, 1280 even ones 118 us - five per CU do not cover the HBM latency)
+    if (ngroups < 4 * cap) return cap;
+    const int rounds = (ngroups + cap - 1) / cap;
+    return (ngroups + rounds - 1) / rounds;
+}
 constexpr int kLnFwdMaxBlocks = 4096;      // 16 per CU (the kernel holds its row in registers: 8 resident workgroups per CU and a second round)
 
 int launch_ln_fwd(const float* x, RowMap rm, const float* gamma, const float* beta, bf16_t* y, float* mean, float* rstd,
                   int M, int D, float eps, hipStream_t s, float* y32) {
     BVC_REQUIRE(D % 4 == 0 && D <= kMaxChunks * 256, "ln_fwd: D=%d unsupported", D);
-    hipLaunchKernelGGL(ln_fwd_kernel, dim3(std::min((M + 3) / 4, kLnFwdMaxBlocks)), dim3(256), 0, s, x, rm, gamma, beta, y, y32, mean, rstd, M, D, eps);
+    if (ln_half_wave_rows(D))
+        hipLaunchKernelGGL(ln_fwd_kernel<32>, dim3(balanced_grid((M + 7) / 8, kLnFwdMaxBlocks)), dim3(256), 0, s, x, rm, gamma, beta, y, y32, mean, rstd, M, D, eps);
+    else
+        hipLaunchKernelGGL(ln_fwd_kernel<64>, dim3(balanced_grid((M + 3) / 4, kLnFwdMaxBlocks)), dim3(256), 0, s, x, rm, gamma, beta, y, y32, mean, rstd, M, D, eps);
     BVC_CHECK_HIP(hipGetLastError());
     return BVC_OK;
 }
@@ -761,14 +802,14 @@ int launch_ln_bwd(const bf16_t* dy, const float* x, RowMap rm, const float* mean
     // rows per workgroup: enough workgroups to keep >= 16 waves per CU streaming (the kernel is HBM-bound and
     // each wave walks its rows serially), few enough that the per-column atomics stay negligible
     const int rpb = ln_bwd_rows_per_block(M);
-    const int nblk = std::min((M + rpb - 1) / rpb, kLnBwdMaxBlocks);
-    const size_t lds = (size_t)8 * D * sizeof(float);
-    if (rpb == 64)
-        hipLaunchKernelGGL(ln_bwd_kernel<64>, dim3(nblk), dim3(256), lds, s, dy, x, rm, mean, rstd, gamma, dres, accumulate, dres_bf, part, M, D);
-    else if (rpb == 16)
-        hipLaunchKernelGGL(ln_bwd_kernel<16>, dim3(nblk), dim3(256), lds, s, dy, x, rm, mean, rstd, gamma, dres, accumulate, dres_bf, part, M, D);
-    else
-        hipLaunchKernelGGL(ln_bwd_kernel<4>, dim3(nblk), dim3(256), lds, s, dy, x, rm, mean, rstd, gamma, dres, accumulate, dres_bf, part, M, D);
+    const int rpg = rpb == 4 && ln_half_wave_rows(D) ? 8 : rpb;          // rows per row group of the instantiation launched below
+    const int nblk = balanced_grid((M + rpg - 1) / rpg, kLnBwdMaxBlocks);
+    const bool half = ln_half_wave_rows(D);
+    const size_t lds = (size_t)(half ? 16 : 8) * D * sizeof(float);
+#define BVC_LN_BWD(RPB_, LPR_) hipLaunchKernelGGL((ln_bwd_kernel<RPB_, LPR_>), dim3(nblk), dim3(256), lds, s, dy, x, rm, mean, rstd, gamma, dres, accumulate, dres_bf, part, M, D)
+    if (rpb == 16) { if (half) BVC_LN_BWD(16, 32); else BVC_LN_BWD(16, 64); }
+    else { if (half) BVC_LN_BWD(8, 32); else BVC_LN_BWD(4, 64); }
+#undef BVC_LN_BWD
     hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * D + 255) / 256, (nblk + 15) / 16), dim3(256), 0, s, part, nblk, D, dgamma, dbeta);
     BVC_CHECK_HIP(hipGetLastError());
     return BVC_OK;

@@ -348,6 +348,8 @@ __global__ __launch_bounds__(256) void labels_kernel(const PixelSrc clip, const 
     float* buf = reinterpret_cast<float*>(smem);   // [C][E]
     const int E = pg.ts * pg.ps * pg.ps, C = pg.C;
     float* stat = buf + C * E;                     // [C][2]
+    // (one workgroup per token on purpose: a grid-stride form with 4096 workgroups measured 1565 vs 1413 us at 256 clips - the
+    //  load -> barrier -> statistics -> barrier -> store chain of a token hides its latency only behind OTHER workgroups)
     const int m = blockIdx.x, b = m / nmask, tok = msk_idx[m];
     const int wp = pg.W / pg.ps, hp = pg.H / pg.ps;
     const int tp = tok / (hp * wp), yp = (tok / wp) % hp, xp = tok % wp;

@@ -100,6 +100,10 @@ PY
            run profdefault 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/profd -- python3 $R/bench.py
            cd $R; find $OUT/profd -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/kernel_stats_default.csv
            find $OUT/profd -name "*kernel_trace.csv" -delete ;;
+    profnobb) rm -rf $OUT/profn; cd /tmp      # the default command without the 64- / 16-clip legs: every launch of a kernel is at the headline batch
+           run profnobb 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/profn -- python3 $R/bench.py --no-by-batch
+           cd $R; find $OUT/profn -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/kernel_stats_no_by_batch.csv
+           find $OUT/profn -name "*kernel_trace.csv" -delete ;;
     prof_jepa) rm -rf $OUT/prof_jepa; cd /tmp
            run prof_jepa 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_jepa -- python3 $R/tools/bench_jepa.py --model vit_large --steps 5 --warmup 2
            cd $R; find $OUT/prof_jepa -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/kernel_stats_jepa_vitl.csv

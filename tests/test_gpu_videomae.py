@@ -160,8 +160,19 @@ def forced_gemm8():
     set of the 256-clip benchmark (gemm8_kernel<256 / 128, NT / NN / TN> in all four epilogue classes, the split-K weight-gradient
     groups) at batches the oracle and the transformers fixtures exist for.  Restored afterwards."""
     old = G.L.set_option("gemm8", 1)
+    # the switch really moves the step's products (results are bit-identical to the 128 x 128 kernels' by design, so the parity
+    # numbers cannot tell): ask the launcher itself which kernel a 2-clip encoder qkv product / decoder weight-gradient group runs on
+    ops = bvc._ops
+    a, w = torch.empty(320, 768, dtype=torch.bfloat16, device=dev), torch.empty(2304, 768, dtype=torch.bfloat16, device=dev)
+    c = torch.empty(320, 2304, dtype=torch.bfloat16, device=dev)
+    assert ops.gemm_kernel_name(ops.gemm_desc(a, w, 320, 2304, 768, ops.EPI["BF16"], c), ops.NT) == "bvc::gemm8_kernel<256, 256, false, false, 0>"
+    dy, x = torch.empty(3136, 384, dtype=torch.bfloat16, device=dev), torch.empty(3136, 1536, dtype=torch.bfloat16, device=dev)
+    d = ops.gemm_desc(dy, x, 384, 1536, 3136, ops.EPI["F32"], torch.empty(384, 1536, device=dev))
+    tile, _split = ops.plan_dw([d])
+    assert tile == 12 and ops.gemm_kernel_name(d, ops.TN, tile) == "bvc::gemm8_kernel<128, 384, true, true, 2>"
     yield
     G.L.set_option("gemm8", old)
+    assert "gemm8" not in ops.gemm_kernel_name(ops.gemm_desc(a, w, 320, 2304, 768, ops.EPI["BF16"], c), ops.NT)
 
 
 def test_base_step_matches_oracle_and_fixture_on_gemm8(golden_dir, forced_gemm8):

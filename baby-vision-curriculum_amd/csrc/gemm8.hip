@@ -42,6 +42,12 @@ namespace {
 
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
+// cache policy of the epilogue's output stores (aux operand of the buffer store: bit 1 = nt, "non-temporal").  Outputs are written
+// once and read by a LATER kernel; left at the default policy they sit in the XCD's 4 MiB L2 next to the operand slabs the
+// resident units share (a round of 32 units writes 4-8 MiB).  -DBVC_G8_ST_AUX=2 marks them streaming (A/B: profiles/r03_i_*).
+#ifndef BVC_G8_ST_AUX
+#define BVC_G8_ST_AUX 0
+#endif
 constexpr uint32_t kInvalidBase = 0x80000000u;   // beyond every operand this kernel accepts (extents < 2 GiB)
 
 struct Unit {
@@ -499,7 +505,7 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const GemmGroup g, const 
                         const auto s0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
                         const auto s1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
                         // even lane rows: own tile-2jp columns, then lane + 16's; odd lane rows: lane - 16's tile-(2jp+1) columns, then own
-                        __builtin_amdgcn_raw_buffer_store_b128(u32x4{s0[0], s1[0], s0[1], s1[1]}, r, o, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(u32x4{s0[0], s1[0], s0[1], s1[1]}, r, o, 0, BVC_G8_ST_AUX);
                     };
                     if (two_out) {      // EPI_GELU: C <- gelu'(pre), C2 <- gelu(pre)
                         float ga[4], gb[4];
@@ -640,12 +646,12 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const GemmGroup g, const 
                                   hi[0] * alpha + bias1[0], hi[1] * alpha + bias1[1], hi[2] * alpha + bias1[2], hi[3] * alpha + bias1[3]};
                     const uint32_t o2 = offs(m, ldc, 2), o4 = offs(m, ldc, 4);
                     auto store_f32 = [&](__amdgpu_buffer_rsrc_t r, uint32_t o) {
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{v[0], v[1], v[2], v[3]}), r, o, 0, 0);
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{v[4], v[5], v[6], v[7]}), r, o, 16, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{v[0], v[1], v[2], v[3]}), r, o, 0, BVC_G8_ST_AUX);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{v[4], v[5], v[6], v[7]}), r, o, 16, BVC_G8_ST_AUX);
                     };
                     auto store_bf16 = [&](__amdgpu_buffer_rsrc_t r, uint32_t o) {
                         __builtin_amdgcn_raw_buffer_store_b128(
-                            u32x4{pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])}, r, o, 0, 0);
+                            u32x4{pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])}, r, o, 0, BVC_G8_ST_AUX);
                     };
                     if constexpr (EC == 0) {
                         // (handled above, in registers)

@@ -129,6 +129,15 @@ PY
              find $OUT/pmcg8/$c -name "*.csv" -size +2M -delete
            done
            unset BVC_G8_CASE; cd $R; cat $OUT/pmc_g8_*.txt ;;
+    pmc_dw) rm -rf $OUT/pmcdw; cd /tmp
+           for c in dec10 dec12 enc10; do
+             export BVC_DW_CASE=$c
+             run pmc_dw_${c}_a 200 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA --output-format csv -d $OUT/pmcdw/$c/a -- python3 $R/tools/dw_only.py
+             run pmc_dw_${c}_c 200 rocprofv3 --kernel-trace --pmc SQ_INSTS_VMEM SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmcdw/$c/c -- python3 $R/tools/dw_only.py
+             python3 $R/tools/pmc_summary.py $OUT/pmcdw/$c/a $OUT/pmcdw/$c/c $OUT/pmc_dw_$c.txt > /dev/null
+             find $OUT/pmcdw/$c -name "*.csv" -size +2M -delete
+           done
+           unset BVC_DW_CASE; cd $R; cat $OUT/pmc_dw_*.txt ;;
     pmc_attn) rm -rf $OUT/pmcattn; cd /tmp
            run pmc_attn_a 200 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA --output-format csv -d $OUT/pmcattn/a -- python3 $R/tools/attn_only.py
            run pmc_attn_b 200 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_SALU SQ_INST_CYCLES_VMEM --output-format csv -d $OUT/pmcattn/b -- python3 $R/tools/attn_only.py

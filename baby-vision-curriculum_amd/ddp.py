@@ -17,8 +17,12 @@ What may be wrapped:
   * a flat module (VideoMAEForPreTraining, jepa.VisionTransformer, jepa.VisionTransformerPredictor): protocol
     ``flat_parameters() / flat_grads() / _bucket_hook / _after_backward``;
   * a COMPOSITE nn.Module that contains flat modules and ordinary parameters (simclr.SimCLRViT = flat ViT trunk + projection
-    head): every flat child gets the bucket hooks; the remaining ("loose") parameters are averaged as one coalesced
-    all-reduce as soon as autograd has accumulated the last of them;
+    head): every flat child gets the bucket hooks; the remaining ("loose") parameters are averaged as ONE coalesced
+    all-reduce per backward, on the communication stream like a bucket: when the first flat child starts reporting ranges
+    if the module declares ``_bvc_loose_before_flat`` (its ordinary parameters sit behind the flat trunk, so autograd has
+    accumulated them by then - SimCLRViT), else from the end-of-backward callback.  Either way it is issued on EVERY rank in
+    EVERY backward (armed by a hook on the module's outputs, not by a parameter hook that may never fire on some rank), a
+    parameter the local backward did not reach contributes zeros, and it RECEIVES the average when any rank reached it;
   * a module whose parameters never receive gradients (the JEPA target encoder): parameters are broadcast, nothing else.
 """
 from __future__ import annotations
@@ -30,6 +34,26 @@ import torch.distributed as dist
 import torch.nn as nn
 
 from . import comm as _comm
+
+
+class _null_ctx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+def _tensors_of(out):
+    """Tensors inside a forward's return value (tensor, tuple / list / dict of them, objects with tensor attributes are not searched)."""
+    if isinstance(out, torch.Tensor):
+        yield out
+    elif isinstance(out, (tuple, list)):
+        for o in out:
+            yield from _tensors_of(o)
+    elif isinstance(out, dict):
+        for o in out.values():
+            yield from _tensors_of(o)
 
 
 def _is_flat(m):
@@ -91,8 +115,10 @@ class DistributedDataParallel(nn.Module):
                 owned.update(id(p) for p in m.parameters())
         self._loose = [p for p in module.parameters() if id(p) not in owned] if isinstance(module, nn.Module) else []
         self._loose_grad = [p for p in self._loose if p.requires_grad]
-        self._loose_seen = 0
-        self._loose_flush_queued = False
+        self._loose_early = bool(getattr(module, "_bvc_loose_before_flat", False)) and bool(self._flats)
+        self._loose_flushed = False
+        self._armed = False           # the end-of-backward callback of the running backward is queued
+        self.joins = 0                # times the compute stream was made to wait for the exchange (once per backward; tests)
         if self._device is not None and self._device.type == "cuda":
             self._native_comm(self._device)       # create the library communicator now (rendezvous + probe), not inside the first backward
         if broadcast_parameters:
@@ -132,9 +158,33 @@ class DistributedDataParallel(nn.Module):
                 o += n
 
     def forward(self, *args, **kwargs):
-        self._loose_seen = 0          # a backward that ended early (exception, a parameter without gradient) must not shift the next one
-        self._loose_flush_queued = False
-        return self.module(*args, **kwargs)
+        # a backward that ended early (exception) must not leave its state to the next one
+        self._armed = False
+        self._loose_flushed = False
+        out = self.module(*args, **kwargs)
+        if self._active() and torch.is_grad_enabled() and (self._loose_grad or self._flats):
+            # The gradient exchange of a backward ends in ONE engine callback (loose-parameter flush, then one join), armed by
+            # whichever comes first: the gradient reaching the module's outputs, a flat child's backward, a loose parameter's hook.
+            # The output hook is the one that fires on every rank whatever the rank-local graph looks like.
+            for t in _tensors_of(out):
+                if t.requires_grad:
+                    t.register_hook(self._output_hook)
+        return out
+
+    def _output_hook(self, grad):
+        self._arm()
+        return grad
+
+    def _arm(self):
+        """Queue the end-of-backward callback once per backward.  False outside an autograd backward (a flat stand-in driven directly)."""
+        if self._armed:
+            return True
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(self._end_of_backward)
+        except RuntimeError:
+            return False
+        self._armed = True
+        return True
 
     # ---- gradient exchange
     def _active(self):
@@ -196,6 +246,8 @@ class DistributedDataParallel(nn.Module):
         lo, hi = offset, offset + count
         if st.fresh:
             st.reduced_ranges, st.fresh = [], False
+            if self._loose_early and not self._loose_flushed:
+                self._flush_loose()       # the head's gradients travel under the trunk's backward
         if st.pending is None:
             st.pending = (lo, hi)
         else:
@@ -224,50 +276,79 @@ class DistributedDataParallel(nn.Module):
             torch.cuda.current_stream(device).wait_stream(self._comm_stream)
 
     def _finish(self, st):
-        """End of one flat module's backward: flush its last bucket and make the compute stream wait for the exchange."""
+        """End of one flat module's backward: flush its last bucket.  The compute stream is NOT made to wait here: the buckets of
+        this module stay in flight under whatever backward work follows (JEPA: the predictor's exchange under the encoder's
+        backward, pretrain_jepa.py:302-304) and the backward ends in one join (`_end_of_backward`)."""
         if st.pending is not None:
             self._reduce(st, *st.pending)
             st.pending = None
+        st.fresh = True
+        if not self._arm():
+            self._end_of_backward()
+
+    def _end_of_backward(self):
+        """Engine callback, once per backward (or called directly when a flat stand-in is driven outside autograd)."""
+        self._armed = False
+        if not self._loose_flushed:
+            self._flush_loose()
+        self._loose_flushed = False
+        if not self._active():
+            return
         if self._native:
             self._native.wait()
         if self._comm_stream is not None:
             self._join(self._comm_stream.device)
-        st.fresh = True
+        self.joins += 1
         if self.profile_buckets and self._timed:
             torch.cuda.current_stream().synchronize()
             self.bucket_log.append([(nbytes, e0.elapsed_time(e1)) for nbytes, e0, e1 in self._timed])
             self._timed = []
 
     def _on_loose_grad(self, _param):
-        """autograd has accumulated one more ordinary parameter.  The coalesced all-reduce of all of them runs ONCE per backward,
-        from an end-of-backward callback of the autograd engine: it does not depend on an exact count of hook firings (a parameter
-        that received no gradient in this backward, or whose requires_grad was toggled after wrapping, would make a counter fire
-        at the wrong moment - or on some ranks only, which is a hang)."""
-        self._loose_seen += 1
-        if not self._loose_flush_queued:
-            self._loose_flush_queued = True
-            torch.autograd.Variable._execution_engine.queue_callback(self._flush_loose)
+        """autograd has accumulated one more ordinary parameter: make sure this backward ends in the callback.  Nothing is counted
+        (a parameter without gradient in this backward, or one whose requires_grad was toggled after wrapping, would make a
+        counter fire at the wrong moment - or on some ranks only, which is a hang)."""
+        self._arm()
 
     def _flush_loose(self):
-        self._loose_flush_queued = False
-        self._loose_seen = 0
-        if not self._active():
+        """ONE coalesced all-reduce of the ordinary parameters' gradients, the same size on every rank in every backward: all
+        parameters that may receive gradients, zeros standing in for the ones this rank's backward did not reach, plus one
+        "reached" flag per parameter.  A parameter whose flag comes back non-zero was reached on SOME rank: every rank then holds
+        the average, also the ranks where `.grad` was None (their optimiser must step it like the others - what torch's DDP does
+        under find_unused_parameters); a parameter no rank reached keeps `.grad = None`.  On a GPU the cat, the collective and the
+        copies back run on the communication stream; the backward's single join covers them."""
+        self._loose_flushed = True
+        if not self._active() or not self._loose_grad:
             return
-        # every rank reduces the SAME list - all parameters that may receive gradients, zeros standing in for the ones this
-        # backward did not reach - so the collective's size never depends on rank-local control flow
-        grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in self._loose_grad]
-        if not grads:
-            return
-        flat = torch.cat([g.reshape(-1).float() for g in grads])
+        ps = self._loose_grad
+        dev = ps[0].device
+        grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in ps]
+        flags = torch.tensor([0.0 if p.grad is None else 1.0 for p in ps], dtype=torch.float32)
+        flat = torch.cat([g.reshape(-1).float() for g in grads] + [flags.to(dev, non_blocking=True)])
         self._all_reduce_avg(flat)
+        side = None
         if flat.is_cuda:
-            self._join(flat.device)      # a few MB: not worth overlapping, and the copies below read it
-        o = 0
-        for p, g in zip(self._loose_grad, grads):
-            n = g.numel()
-            if p.grad is not None:
-                p.grad.copy_(flat[o:o + n].view_as(g))
-            o += n
+            side = self._native.torch_stream() if self._native else self._comm_stream
+            flat.record_stream(side)
+        nflag = len(ps)
+        reached = flat[flat.numel() - nflag:]
+        if any(p.grad is None for p in ps):
+            reached_host = reached.cpu() if not flat.is_cuda else None
+            if flat.is_cuda:
+                with torch.cuda.stream(side):
+                    reached_host = reached.to("cpu")          # synchronises the communication stream only, and only on this rare path
+        ctx = torch.cuda.stream(side) if side is not None else _null_ctx()
+        with ctx:
+            o = 0
+            for i, (p, g) in enumerate(zip(ps, grads)):
+                n = g.numel()
+                if p.grad is not None:
+                    p.grad.copy_(flat[o:o + n].view_as(g))
+                elif float(reached_host[i]) > 0.0:
+                    p.grad = flat[o:o + n].view_as(p).to(p.dtype).clone()
+                    if side is not None:
+                        p.grad.record_stream(torch.cuda.current_stream(dev))
+                o += n
 
     # ---- reporting (bench.py): algorithm bandwidth and ring bus bandwidth per bucket of the logged backwards
     def bucket_report(self):

@@ -167,6 +167,10 @@ class SimCLRViT(nn.Module):
     num_frames=1, tubelet 1), features = mean over tokens, ``fc`` = the SimCLR head of pretrain_simclr.py:71-77.
     ``forward(x)`` takes the (2B, C, H, W) view the reference's forward_loss builds (:322-324) and returns (2B, p)."""
 
+    # the head's ordinary parameters sit BEHIND the flat trunk: autograd has accumulated their gradients when the trunk's backward
+    # starts, so the data-parallel wrapper sends them under it (ddp.py)
+    _bvc_loose_before_flat = True
+
     def __init__(self, model_name="vit_base", image_size=224, patch_size=16, pred_emb_dim=None):
         super().__init__()
         from . import jepa

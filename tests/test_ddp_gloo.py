@@ -213,7 +213,8 @@ def _body_jepa(rank, world, bvc):
     views_ok = all(p.grad is not None and p.grad.data_ptr() == enc.flat_grads()[off:].data_ptr()
                    for (name, off, _s), p in zip(enc._layout, enc.parameters()))
     return (g_enc, g_pred, enc.flat_parameters().clone(), pred.flat_parameters().clone(), tgt.flat_parameters().clone(),
-            float(bvc.AllReduce.apply(loss.detach())), [list(wenc.reduced_ranges), list(wpred.reduced_ranges)], views_ok)
+            float(bvc.AllReduce.apply(loss.detach())), [list(wenc.reduced_ranges), list(wpred.reduced_ranges)], views_ok,
+            (wenc.joins, wpred.joins, wtgt.joins))
 
 
 SIM = dict(din=10, dh=12, p=8, T=0.1, per_rank=4)
@@ -308,7 +309,61 @@ def _body_robust(rank, world, bvc):
         log.restore()
 
 
-BODIES = {"videomae": _body_videomae, "jepa": _body_jepa, "simclr": _body_simclr, "robust": _body_robust}
+def _one_rank_losses(model, x, rank_uses_extra):
+    model.use_extra = rank_uses_extra
+    return model(x).pow(2).mean()
+
+
+def _body_unused_on_one_rank(rank, world, bvc):
+    """`extra` enters the graph on rank 0 only.  Every rank must still issue the coalesced all-reduce (a flush armed by a parameter
+    hook alone would leave a rank that reached no ordinary parameter out of the collective: a hang), and rank 1 must RECEIVE the
+    average for `extra` - its optimiser steps it like rank 0's, or the replicas diverge."""
+    log = _CallLog()
+    try:
+        model = _SimModelUnused(bvc, seed=21 + rank)
+        ddp = bvc.ddp.DistributedDataParallel(model, bucket_cap_mb=1e-4)
+        n = 2 * SIM["per_rank"]
+        outs = []
+        for it in range(2):
+            for p in model.parameters():
+                p.grad = None
+            x = _sim_batch(n * world, seed=41 + it)[n * rank:n * rank + n]
+            model.use_extra = rank == 0
+            ddp(x).pow(2).mean().backward()
+            outs.append((_flat_grad_of(model.trunk), torch.cat([p.grad.reshape(-1) for p in model.fc.parameters()]),
+                         None if model.extra.grad is None else model.extra.grad.clone()))
+        return (outs, list(log.calls), ddp.joins)
+    finally:
+        log.restore()
+
+
+class _HeadOnly(nn.Module):
+    """ordinary parameters only, one of which no rank but rank 0 reaches; the trunk-less shape (no flat child ever arms the flush)"""
+
+    def __init__(self):
+        super().__init__()
+        torch.manual_seed(5)
+        self.a = nn.Linear(6, 6)
+        self.b = nn.Parameter(torch.ones(6))
+        self.use_b = True
+
+    def forward(self, x):
+        y = self.a(x)
+        return y * self.b if self.use_b else y
+
+
+def _body_head_only(rank, world, bvc):
+    model = _HeadOnly()
+    ddp = bvc.ddp.DistributedDataParallel(model)
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(4 * world, 6, generator=g)[4 * rank:4 * rank + 4]
+    model.use_b = rank == 0
+    ddp(x).pow(2).mean().backward()
+    return (model.a.weight.grad.clone(), model.a.bias.grad.clone(), None if model.b.grad is None else model.b.grad.clone(), ddp.joins)
+
+
+BODIES = {"videomae": _body_videomae, "jepa": _body_jepa, "simclr": _body_simclr, "robust": _body_robust,
+          "unused_on_one_rank": _body_unused_on_one_rank, "head_only": _body_head_only}
 
 
 def _entry(body, rank, world, port, q):
@@ -402,7 +457,10 @@ def test_jepa_three_wraps_gradients_and_ema_match_global_batch():
         enc.flat_parameters().add_(ge_, alpha=-0.1)
         pred.flat_parameters().add_(gp_, alpha=-0.1)
     _ema(enc, tgt)
-    for rank, (g_enc, g_pred, p_enc, p_pred, p_tgt, mean_loss, ranges, views_ok) in enumerate(got):
+    for rank, (g_enc, g_pred, p_enc, p_pred, p_tgt, mean_loss, ranges, views_ok, joins) in enumerate(got):
+        # one join per wrapper and backward, at the END of the backward: the predictor's buckets are not waited for when its own
+        # backward ends (they travel under the encoder's); the target encoder never exchanges anything
+        assert joins == (1, 1, 0), joins
         assert float((g_enc - ge_).norm() / ge_.norm()) < 1e-5, rank
         assert float((g_pred - gp_).norm() / gp_.norm()) < 1e-5, rank
         assert torch.allclose(p_enc, enc.flat_parameters(), rtol=1e-5, atol=1e-6)
@@ -477,3 +535,44 @@ def test_loose_parameter_without_gradient_and_collective_call_order():
             if ge is not None:
                 assert torch.allclose(ge, model.extra.grad, rtol=1e-4, atol=1e-6), (it, rank)
             assert abs(ls - float(loss)) < 1e-5 * abs(float(loss))
+
+
+@pytest.mark.timeout(600)
+def test_loose_parameter_reached_on_one_rank_only():
+    """ADVICE (round 3): the coalesced all-reduce of the ordinary parameters must be symmetric across ranks whatever the rank-local
+    graph reaches, and a rank whose backward left `.grad = None` must still receive the average."""
+    sys.path.insert(0, ROOT)
+    bvc = _load()
+    world = 2
+    got = _run("unused_on_one_rank", world)
+    (o0, calls0, j0), (o1, calls1, j1) = got
+    assert calls0 == calls1, "ranks issued different collective sequences"
+    assert j0 == j1 == 2                                   # one join per backward
+    model = _SimModelUnused(bvc, seed=21)                  # rank 0's parameters
+    n = 2 * SIM["per_rank"]
+    for it in range(2):
+        xs = _sim_batch(n * world, seed=41 + it)
+        want_t, want_l, want_e = 0, 0, 0
+        for r in range(world):                              # mean over ranks of the per-rank gradients
+            for p in model.parameters():
+                p.grad = None
+            _one_rank_losses(model, xs[n * r:n * r + n], r == 0).backward()
+            want_t = want_t + _flat_grad_of(model.trunk) / world
+            want_l = want_l + torch.cat([p.grad.reshape(-1) for p in model.fc.parameters()]) / world
+            if model.extra.grad is not None:
+                want_e = want_e + model.extra.grad / world
+        for rank, outs in enumerate((o0, o1)):
+            gt, gl, ge = outs[it]
+            assert float((gt - want_t).norm() / want_t.norm()) < 2e-5, (it, rank)
+            assert float((gl - want_l).norm() / want_l.norm()) < 2e-5, (it, rank)
+            assert ge is not None, f"rank {rank} never received the gradient of the parameter only rank 0 reached"
+            assert torch.allclose(ge, want_e, rtol=1e-4, atol=1e-7), (it, rank)
+
+
+@pytest.mark.timeout(600)
+def test_ordinary_module_with_a_parameter_one_rank_reaches():
+    got = _run("head_only", 2)
+    (w0, b0, e0, j0), (w1, b1, e1, j1) = got
+    assert torch.equal(w0, w1) and torch.equal(b0, b1)
+    assert e0 is not None and e1 is not None and torch.equal(e0, e1)
+    assert j0 == j1 == 1

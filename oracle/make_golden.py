@@ -313,9 +313,60 @@ def embedding_fixture():
         json.dump({"transformers": ver, "torch": torch.__version__, "cases": cases}, f, indent=1)
 
 
+def bf16_policy_fixture():
+    """Numbers of the bf16-OPERAND oracle (oracle/videomae_oracle_bf16.py) at the cases the GPU tests run, and its pin.
+
+    (1) per case: loss and the three grad_logger norms of the fp32 step, of the step under the build's operand policy (BUILD) and
+        under autocast proper (BUILD + linear outputs and weight gradients rounded);
+    (2) the pin: transformers' own VideoMAEForPreTraining run under `torch.autocast("cpu", dtype=torch.bfloat16)` on the same
+        weights and clips.  CPU autocast casts the linear layers and SDPA to bf16 (operands AND outputs; GELU then runs on bf16
+        values) and keeps LayerNorm / the loss in f32 - the closest executable relative of the derived CUDA policy (SURVEY.md
+        section 8a).  It is not the same policy as BUILD (outputs rounded, bf16 residual updates), so the check is on the SIGNED
+        deviations of the probe norms from the fp32 step: same sign and same magnitude class as the oracle's autocast mode."""
+    from oracle import videomae_oracle_bf16 as vb
+    cases = {}
+    for name, cfg, batch, seed, wseed, ratio in (("tiny_s0", vo.TINY, 2, 0, 0, 0.75), ("base_b2_s0", vo.BASE, 2, 0, 0, 0.9),
+                                                 ("base_b2_s1", vo.BASE, 2, 1, 1, 0.9), ("base_b16_s0", vo.BASE, 16, 0, 0, 0.9)):
+        params = vo.make_params(cfg, seed=wseed)
+        pixels, mask = vo.synthetic_batch(cfg, batch, seed, ratio)
+        l32, g32 = vo.step(cfg, params, pixels, mask)
+        entry = {"batch": batch, "seed": seed, "weight_seed": wseed, "mask_ratio": ratio,
+                 "fp32": {"loss": float(l32), "probes": vb.probe_norms(g32)}}
+        off_l, off_g = vb.step(cfg, params, pixels, mask, vb.F32)
+        assert abs(float(off_l) - float(l32)) < 1e-6 * float(l32)
+        assert max(abs(a - b) / b for a, b in zip(vb.probe_norms(off_g), vb.probe_norms(g32))) < 1e-6, "all switches off must be the fp32 step"
+        for tag, pol in (("build", vb.BUILD), ("autocast", vb.Policy(True, True, True, True, True))):
+            l, g = vb.step(cfg, params, pixels, mask, pol)
+            entry[tag] = {"loss": float(l), "probes": vb.probe_norms(g)}
+        if batch <= 2:
+            model, ver = hf_model(cfg, params)
+            with torch.autocast("cpu", dtype=torch.bfloat16):
+                out = model(pixels, bool_masked_pos=mask)
+            out.loss.float().backward()
+            hg = {k: v.grad.float() for k, v in model.named_parameters()}
+            entry["transformers_cpu_autocast"] = {"loss": float(out.loss), "probes": vb.probe_norms(hg), "transformers": ver}
+            ref = entry["fp32"]["probes"]
+            dev_hf = [(a - b) / b for a, b in zip(entry["transformers_cpu_autocast"]["probes"], ref)]
+            dev_or = [(a - b) / b for a, b in zip(entry["autocast"]["probes"], ref)]
+            print(f"[bf16 {name}] probe deviations from fp32: transformers under CPU autocast {['%+.2e' % d for d in dev_hf]}, "
+                  f"oracle autocast mode {['%+.2e' % d for d in dev_or]}, oracle BUILD mode "
+                  f"{['%+.2e' % ((a - b) / b) for a, b in zip(entry['build']['probes'], ref)]}")
+            assert abs(float(out.loss) - float(l32)) < 2e-3 * float(l32)
+            if cfg.hidden_size >= 768:
+                for dh, do in zip(dev_hf, dev_or):     # same sign, same size class (the policies differ in the residual adds)
+                    assert abs(dh - do) < 6e-4, (name, dev_hf, dev_or)
+        cases[name] = entry
+    with open(os.path.join(GOLD, "videomae_bf16_policy.json"), "w") as f:
+        json.dump({"source": "oracle/videomae_oracle_bf16.py; pretrain_videomae.py:306-308 (autocast), loggingtools.py:98-119 (probes)",
+                   "probe_keys": list(vo.GRAD_PROBES), "torch": torch.__version__, "cases": cases}, f, indent=1)
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     torch.manual_seed(0)
+    if "--bf16-policy" in sys.argv:
+        bf16_policy_fixture()
+        return
     if "--full-size" in sys.argv:      # the BASELINE-size pins only (minutes of CPU): VideoMAE-base B=16, JEPA ViT-L, SimCLR 512 / 8192 rows
         one_case("base_b16_s0", vo.BASE, batch=16, seed=0, mask_ratio=0.9)
         jepa_fixture(large=True)

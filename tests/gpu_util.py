@@ -1,5 +1,6 @@
 """Helpers for the -m gpu parity tests: thin Python over the C ABI of libbvc_hip.so (include/bvc.h)."""
 import ctypes
+import os
 
 import torch
 
@@ -59,3 +60,14 @@ def rel_err(a, b):
 def bf16_randn(*shape, scale=1.0, seed=0, device="cuda"):
     g = torch.Generator().manual_seed(seed)
     return (torch.randn(*shape, generator=g) * scale).to(torch.bfloat16).to(device)
+
+
+PARITY_REPORT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "parity_report.txt")
+
+
+def log_parity(msg):
+    """One line of the parity report (gpurun_out/parity_report.txt; copies are committed under profiles/)."""
+    os.makedirs(os.path.dirname(PARITY_REPORT), exist_ok=True)
+    with open(PARITY_REPORT, "a") as f:
+        f.write(msg + "\n")
+    print(msg)

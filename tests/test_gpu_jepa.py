@@ -18,6 +18,7 @@ from oracle import jepa_oracle as jo   # noqa: E402
 
 bvc = G.bvc
 dev = torch.device("cuda:0")
+PROBE_BAR_TOY = 5e-3
 
 
 def _modules(cfg, enc_p, pred_p, tgt_p):
@@ -61,23 +62,38 @@ def test_train_step_matches_oracle_and_fixture(golden_dir, idx):
     loss = bvc.AllReduce.apply(loss)
     (loss * scale).backward()
     torch.cuda.synchronize()
-    assert G.rel_err(h.cpu(), rh) < 2e-2
-    assert G.rel_err(z.detach().cpu(), rz) < 2e-2
+    tag = f"jepa {c['case']}"
+    eh, ez = G.rel_err(h.cpu(), rh), G.rel_err(z.detach().cpu(), rz)
     rel = abs(float(loss) - float(rloss)) / float(rloss)
+    G.log_parity(f"[{tag}] loss hip {float(loss):.7f} oracle {float(rloss):.7f} rel {rel:.2e}; vs the reference modules' fixture rel "
+                 f"{abs(float(loss) - c['loss']) / c['loss']:.2e}; targets h rel {eh:.2e}, predictions z rel {ez:.2e}")
+    assert eh < 2e-2 and ez < 2e-2
     assert rel < 1e-3, (float(loss), float(rloss))
     assert abs(float(loss) - c["loss"]) / c["loss"] < 1e-3          # the number the reference's own modules produced
     gmax = max(float(g.norm()) for g in list(rge.values()) + list(rgp.values()))
+    worst = ("", 0.0)
     for mod, ref in ((enc, rge), (pred, rgp)):
         for k, p in mod.named_parameters():
             if not p.requires_grad:
                 assert p.grad is None
                 continue
             e = float((p.grad.float().cpu() - ref[k]).norm() / (ref[k].norm() + 1e-3 * gmax))
+            if e > worst[1]:
+                worst = (k, e)
             assert e < 5e-2, (k, e)
-    # the predictive entry point's grad_logger probes: first / last qkv weight norms
+    G.log_parity(f"[{tag}] worst per-tensor gradient rel L2 {worst[1]:.2e} ({worst[0]})")
+    # the predictive entry point's grad_logger probes (pretraining/predictive/loggingtools.py:98-112): first / last qkv weight norms.
+    # north_star's bar is 1e-3 on the probe norms; the toy configurations (64 - 128 wide: a norm averages the bf16 rounding of
+    # ~100x fewer elements than ViT-B's) are given PROBE_BAR_TOY and their measured value is printed next to it.
+    wide = cfg.embed_dim >= 768
+    bar = 1e-3 if wide else PROBE_BAR_TOY
     for k in ("blocks.0.attn.qkv.weight", f"blocks.{cfg.depth - 1}.attn.qkv.weight"):
-        gn = float(dict(enc.named_parameters())[k].grad.norm())
-        assert abs(gn - float(rge[k].norm())) / float(rge[k].norm()) < 5e-3, k
+        gn, rn = float(dict(enc.named_parameters())[k].grad.norm()), float(rge[k].norm())
+        fx = c["grad_first_qkv" if k.startswith("blocks.0.") else "grad_last_qkv"] * scale
+        e = (gn - rn) / rn
+        G.log_parity(f"[{tag}] grad-norm {k}: hip {gn:.6e} oracle {rn:.6e} rel {e:+.2e} (bar {bar:.0e}, margin {bar / max(abs(e), 1e-12):.1f}x); "
+                     f"vs the reference modules' fixture rel {(gn - fx) / fx:+.2e}")
+        assert abs(e) < bar, (k, e)
 
 
 def test_reference_formulation_of_targets_and_loss():

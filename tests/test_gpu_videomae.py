@@ -43,7 +43,29 @@ def _tap(model, name, shape):
     return model.tap(name).view(shape).float().cpu()
 
 
-def _check_step(tag, cfg, B, seed, ratio, wseed=0, grad_scale=1.0, fixture=None):
+OWN_BAR = 3e-4     # |probe norm - bf16-operand oracle's| / norm: the share of a deviation that is this build's own
+
+
+def _bf16_case(golden_dir, name):
+    """Loss and probe norms of the oracle's bf16-OPERAND step (oracle/videomae_oracle_bf16.py, the build's operand policy) for a
+    fixture case, from tests/golden/videomae_bf16_policy.json (generated next to transformers' own CPU-autocast run)."""
+    with open(os.path.join(golden_dir, "videomae_bf16_policy.json")) as f:
+        return json.load(f)["cases"][name]
+
+
+def _log_probe_decomposition(tag, k, i, gn, ref32, bf, scale=1.0):
+    """One probe norm against BOTH oracles: the signed deviation from the fp32 step (bar 1e-3), what the bf16-operand oracle
+    shows for the same inputs (any bf16-operand run - the reference under CUDA autocast included - deviates that much), and the
+    remainder, which is this build's own and is held to OWN_BAR."""
+    o32, obf = bf["fp32"]["probes"][i] * scale, bf["build"]["probes"][i] * scale
+    d_hip, d_bf = (gn - ref32) / ref32, (obf - o32) / o32
+    own = (gn - obf) / obf
+    _log(f"[{tag}]   {k.split('.')[-2]}: hip vs fp32 {d_hip:+.2e} | bf16-operand oracle vs fp32 {d_bf:+.2e} | hip vs bf16-operand oracle {own:+.2e} "
+         f"(own bar {OWN_BAR:.0e}, margin {OWN_BAR / max(abs(own), 1e-12):.1f}x)")
+    assert abs(own) < OWN_BAR, (k, own)
+
+
+def _check_step(tag, cfg, B, seed, ratio, wseed=0, grad_scale=1.0, fixture=None, bf16=None):
     params = vo.make_params(cfg, seed=wseed)
     pixels, mask = vo.synthetic_batch(cfg, B, seed, ratio)
     taps = {}
@@ -95,6 +117,8 @@ def _check_step(tag, cfg, B, seed, ratio, wseed=0, grad_scale=1.0, fixture=None)
         if fixture is not None:
             fn = fixture["grad_probes"][k] * grad_scale
             _log(f"[{tag}]   vs transformers fixture {fn:.6e} rel {abs(gn - fn) / fn:.2e}")
+        if bf16 is not None:
+            _log_probe_decomposition(tag, k, vo.GRAD_PROBES.index(k), gn, rn, bf16, grad_scale)
     if fixture is not None:
         fr = abs(loss - fixture["loss"]) / fixture["loss"]
         _log(f"[{tag}] loss vs transformers fixture {fixture['loss']:.7f} rel {fr:.2e}")
@@ -115,7 +139,7 @@ def test_tiny_step_odd_batch_and_scale():
 def test_base_step_matches_oracle_and_fixture(golden_dir, case):
     with open(os.path.join(golden_dir, f"videomae_{case}.json")) as f:
         fx = json.load(f)
-    _check_step(case, vo.BASE, fx["batch"], fx["seed"], fx["mask_ratio"], wseed=fx["weight_seed"], fixture=fx)
+    _check_step(case, vo.BASE, fx["batch"], fx["seed"], fx["mask_ratio"], wseed=fx["weight_seed"], fixture=fx, bf16=_bf16_case(golden_dir, case))
 
 
 def test_base_b16_matches_transformers_fixture(golden_dir, tag="base_b16_s0"):
@@ -142,6 +166,7 @@ def test_base_b16_matches_transformers_fixture(golden_dir, tag="base_b16_s0"):
         e = abs(gn - rn) / rn
         _log(f"[{tag}] grad-norm {k}: hip {gn:.6e} transformers {rn:.6e} rel {e:.2e} (bar 1e-3, margin {1e-3 / max(e, 1e-12):.1f}x)")
         assert e < 1e-3, (k, e)
+        _log_probe_decomposition(tag, k, vo.GRAD_PROBES.index(k), gn, rn, _bf16_case(golden_dir, "base_b16_s0"))
     gmax = max(fx["grad_l2"].values())
     worst = ("", 0.0)
     assert set(fx["grad_l2"]) == set(named)
@@ -160,6 +185,17 @@ def forced_gemm8():
     set of the 256-clip benchmark (gemm8_kernel<256 / 128, NT / NN / TN> in all four epilogue classes, the split-K weight-gradient
     groups) at batches the oracle and the transformers fixtures exist for.  Restored afterwards."""
     old = G.L.set_option("gemm8", 1)
+    try:
+        yield from _forced_gemm8_body()
+    finally:
+        G.L.set_option("gemm8", old)       # process-wide switch: restored whatever an assertion above did
+    ops = bvc._ops
+    a, w = torch.empty(320, 768, dtype=torch.bfloat16, device=dev), torch.empty(2304, 768, dtype=torch.bfloat16, device=dev)
+    c = torch.empty(320, 2304, dtype=torch.bfloat16, device=dev)
+    assert "gemm8" not in ops.gemm_kernel_name(ops.gemm_desc(a, w, 320, 2304, 768, ops.EPI["BF16"], c), ops.NT)
+
+
+def _forced_gemm8_body():
     # the switch really moves the step's products (results are bit-identical to the 128 x 128 kernels' by design, so the parity
     # numbers cannot tell): ask the launcher itself which kernel a 2-clip encoder qkv product / decoder weight-gradient group runs on
     ops = bvc._ops
@@ -171,8 +207,6 @@ def forced_gemm8():
     tile, _split = ops.plan_dw([d])
     assert tile == 12 and ops.gemm_kernel_name(d, ops.TN, tile) == "bvc::gemm8_kernel<128, 384, true, true, 2>"
     yield
-    G.L.set_option("gemm8", old)
-    assert "gemm8" not in ops.gemm_kernel_name(ops.gemm_desc(a, w, 320, 2304, 768, ops.EPI["BF16"], c), ops.NT)
 
 
 def test_base_step_matches_oracle_and_fixture_on_gemm8(golden_dir, forced_gemm8):

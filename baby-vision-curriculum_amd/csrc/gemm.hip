@@ -443,6 +443,7 @@ __global__ __launch_bounds__(256, LB) void gemm_kernel(const GemmGroup g) {
 static void tile_dims(int cfg, int& bm, int& bn) {
     if (cfg == 10 || cfg == 11) { bm = 256; bn = cfg == 10 ? 256 : 128; return; }    // gemm8.hip
     if (cfg == 12) { bm = 128; bn = 384; return; }                                     // gemm8.hip, weight gradients of 384-multiples
+    if (cfg == 14) { bm = 128; bn = 256; return; }                                     // gemm_pp.hip: 128 x 256 units, the two wave rows take turns
     bm = cfg == 2 ? 64 : 128;
     bn = cfg == 0 ? 128 : 64;
 }
@@ -457,6 +458,7 @@ int gemm_pick_tile(const GemmProblem* probs, int nprob, int tile_cfg) {
     if (tile_cfg == 6 || tile_cfg == 7) return tile_cfg - 6;     // the persistent kernel: 128x128 / 128x64 tiles
     if (tile_cfg == 9) return 0;                                  // persistent 128x128 with deferred stores
     if (tile_cfg >= 10 && tile_cfg <= 12) return tile_cfg;        // gemm8.hip: 256x256 / 256x128 / 128x384
+    if (tile_cfg == 14) return tile_cfg;                          // gemm_pp.hip
     if (tile_cfg >= 0) return tile_cfg;
     // Measured on MI355X (profiles/r01_b_microbench.json): a workgroup's speed is set by its L2->LDS fill
     // rate (~70 GB/s per CU), so the big tile (64 FLOP/B) wins once it alone covers the 256 CUs ~1.5x;
@@ -565,6 +567,9 @@ int launch_gemm_big_nt(const GemmProblem& p, int cfg, hipStream_t stream);   // 
 int launch_gemm_persist(const GemmGroup& g, GemmLayout layout, int cfg, hipStream_t stream, int defer);
 // gemm8.hip: 256 x bn tiles, one 512-thread workgroup per CU; returns 1 when the group is not eligible
 int launch_gemm8(const GemmGroup& g, GemmLayout layout, int bn, hipStream_t stream);
+// experiments/gemm_pp.hip (experiments build only): 128 x 256 units, K loop of one wave row under the epilogue of the other;
+// built and measured in round 4 (profiles/r04_d_*): correct, bit-identical, and NOT faster - see its header
+int launch_gemm_pp(const GemmGroup& g, GemmLayout layout, hipStream_t stream);
 
 // Which products go to the 256-row persistent kernel (gemm8.hip) when the caller leaves the tile choice open.  Fitted to the
 // same-process A/Bs of every product of the step at 16, 64 and 256 clips (profiles/r02_e_gemm8_ab_b{16,64,256}.txt, tools/gemm8_ab.py):
@@ -661,6 +666,15 @@ int launch_gemm(const GemmProblem* probs, int nprob, GemmLayout layout, int tile
     }
     g.tile_start[nprob] = total;
     for (int i = nprob; i < kMaxGroup; ++i) { g.prob[i] = probs[0]; g.panel[i] = g.panel[0]; g.tile_start[i + 1] = total; }
+    if (cfg == 14) {
+#ifdef BVC_EXPERIMENTS
+        const int rc = launch_gemm_pp(g, layout, stream);
+        BVC_REQUIRE(rc != 1, "launch_gemm: tile config 14 (ping-pong kernel) does not take this problem");
+        return rc;
+#else
+        BVC_REQUIRE(false, "launch_gemm: tile config 14 exists only in a -DBVC_EXPERIMENTS build (csrc/experiments/gemm_pp.hip)");
+#endif
+    }
     if (cfg >= 10 && cfg <= 12) {
         const int rc = launch_gemm8(g, layout, cfg == 10 ? 256 : cfg == 11 ? 128 : 384, stream);
         if (rc == 1 && auto_g8) {     // the selection and the kernel's own eligibility test disagree: never an error for the caller

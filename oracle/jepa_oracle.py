@@ -121,7 +121,32 @@ def make_params(shapes, cfg: JepaConfig, seed: int):
     return out
 
 
-def _block(x, p, prefix, heads, eps):
+def _block_bf16(x, p, prefix, heads, eps, pol):
+    """`_block` under a bf16-operand policy (videomae_oracle_bf16.Policy): operands of every product rounded as the policy says,
+    f32 accumulation, f32 LayerNorm / softmax / residual stream; the same custom autograd functions as the VideoMAE oracle."""
+    from . import videomae_oracle_bf16 as vb
+    B, N, D = x.shape
+    d = D // heads
+    h = F.layer_norm(x, (D,), p[prefix + "norm1.weight"], p[prefix + "norm1.bias"], eps)
+    qkv = vb._Round.apply(vb.linear(h, p[prefix + "attn.qkv.weight"], p[prefix + "attn.qkv.bias"], pol), pol)
+    qkv = qkv.reshape(B, N, 3, heads, d).permute(2, 0, 3, 1, 4)
+    y = vb._Attention.apply(qkv[0], qkv[1], qkv[2], pol).transpose(1, 2).reshape(B, N, D)
+    x = x + vb.linear(y, p[prefix + "attn.proj.weight"], p[prefix + "attn.proj.bias"], pol)
+    h = F.layer_norm(x, (D,), p[prefix + "norm2.weight"], p[prefix + "norm2.bias"], eps)
+    h = vb._Gelu.apply(vb.linear(h, p[prefix + "mlp.fc1.weight"], p[prefix + "mlp.fc1.bias"], pol), pol)
+    return x + vb.linear(h, p[prefix + "mlp.fc2.weight"], p[prefix + "mlp.fc2.bias"], pol, round_dx=False)
+
+
+def _lin(x, w, b, pol):
+    if pol is None:
+        return F.linear(x, w, b)
+    from . import videomae_oracle_bf16 as vb
+    return vb.linear(x, w, b, pol)
+
+
+def _block(x, p, prefix, heads, eps, pol=None):
+    if pol is not None:
+        return _block_bf16(x, p, prefix, heads, eps, pol)
     B, N, D = x.shape
     d = D // heads
     h = F.layer_norm(x, (D,), p[prefix + "norm1.weight"], p[prefix + "norm1.bias"], eps)
@@ -144,47 +169,56 @@ def repeat_interleave_batch(x, B, repeat):
     return torch.cat([torch.cat([x[i * B:(i + 1) * B] for _ in range(repeat)], dim=0) for i in range(N)], dim=0)
 
 
-def encoder_forward(cfg: JepaConfig, p, imgs, masks=None):
-    """imgs (B, T, C, H, W); masks: list of (B, N) int64 index tensors or None."""
-    x = F.conv3d(imgs.permute(0, 2, 1, 3, 4), p["patch_embed.proj.weight"], p["patch_embed.proj.bias"],
-                 stride=(cfg.tubelet_size, cfg.patch_size, cfg.patch_size)).flatten(2).transpose(1, 2)
+def encoder_forward(cfg: JepaConfig, p, imgs, masks=None, pol=None):
+    """imgs (B, T, C, H, W); masks: list of (B, N) int64 index tensors or None.  pol: bf16-operand policy (None = fp32)."""
+    if pol is None:
+        x = F.conv3d(imgs.permute(0, 2, 1, 3, 4), p["patch_embed.proj.weight"], p["patch_embed.proj.bias"],
+                     stride=(cfg.tubelet_size, cfg.patch_size, cfg.patch_size)).flatten(2).transpose(1, 2)
+    else:        # the same convolution as a product over patches (k order c, dt, dy, dx = the Conv3d weight's layout)
+        B, T, C, H, W = imgs.shape
+        ts, ps = cfg.tubelet_size, cfg.patch_size
+        pt = imgs.permute(0, 2, 1, 3, 4).reshape(B, C, T // ts, ts, H // ps, ps, W // ps, ps)
+        pt = pt.permute(0, 2, 4, 6, 1, 3, 5, 7).reshape(B, -1, C * ts * ps * ps)
+        x = _lin(pt, p["patch_embed.proj.weight"].reshape(cfg.embed_dim, -1), p["patch_embed.proj.bias"], pol)
     x = x + p["pos_embed"]
     if masks is not None:
         x = apply_masks(x, masks)
     for i in range(cfg.depth):
-        x = _block(x, p, f"blocks.{i}.", cfg.num_heads, cfg.eps)
+        x = _block(x, p, f"blocks.{i}.", cfg.num_heads, cfg.eps, pol)
     return F.layer_norm(x, (cfg.embed_dim,), p["norm.weight"], p["norm.bias"], cfg.eps)
 
 
-def predictor_forward(cfg: JepaConfig, p, x, masks_x, masks):
+def predictor_forward(cfg: JepaConfig, p, x, masks_x, masks, pol=None):
     B = len(x) // len(masks_x)
-    x = F.linear(x, p["predictor_embed.weight"], p["predictor_embed.bias"])
+    x = _lin(x, p["predictor_embed.weight"], p["predictor_embed.bias"], pol)
     x = x + apply_masks(p["predictor_pos_embed"].repeat(B, 1, 1), masks_x)
     n_ctx = x.shape[1]
     pos = repeat_interleave_batch(apply_masks(p["predictor_pos_embed"].repeat(B, 1, 1), masks), B, repeat=len(masks_x))
     pred = p["mask_token"].repeat(pos.size(0), pos.size(1), 1) + pos
     x = torch.cat([x.repeat(len(masks), 1, 1), pred], dim=1)
     for i in range(cfg.pred_depth):
-        x = _block(x, p, f"predictor_blocks.{i}.", cfg.num_heads, cfg.eps)
+        x = _block(x, p, f"predictor_blocks.{i}.", cfg.num_heads, cfg.eps, pol)
     x = F.layer_norm(x, (cfg.pred_dim,), p["predictor_norm.weight"], p["predictor_norm.bias"], cfg.eps)
-    return F.linear(x[:, n_ctx:], p["predictor_proj.weight"], p["predictor_proj.bias"])
+    return _lin(x[:, n_ctx:], p["predictor_proj.weight"], p["predictor_proj.bias"], pol)
 
 
-def targets(cfg: JepaConfig, tgt_p, imgs, masks_enc, masks_pred):
+def targets(cfg: JepaConfig, tgt_p, imgs, masks_enc, masks_pred, pol=None):
     with torch.no_grad():
-        h = encoder_forward(cfg, tgt_p, imgs)
+        h = encoder_forward(cfg, tgt_p, imgs, pol=pol)
         h = F.layer_norm(h, (h.size(-1),))
         B = len(h)
         return repeat_interleave_batch(apply_masks(h, masks_pred), B, repeat=len(masks_enc))
 
 
-def step(cfg: JepaConfig, enc_p, pred_p, tgt_p, imgs, masks_enc, masks_pred, grad_scale=1.0):
-    """train_step's forward/backward (pretrain_jepa.py:383-418).  Returns loss, encoder grads, predictor grads, z, h."""
+def step(cfg: JepaConfig, enc_p, pred_p, tgt_p, imgs, masks_enc, masks_pred, grad_scale=1.0, pol=None):
+    """train_step's forward/backward (pretrain_jepa.py:383-418).  Returns loss, encoder grads, predictor grads, z, h.
+    pol: a videomae_oracle_bf16.Policy - the same step with bf16 OPERANDS (what the reference computes under CUDA autocast,
+    pretrain_jepa.py:404-405, and what the build computes); None = the fp32 step."""
     ep = {k: v.detach().clone().requires_grad_(k != "pos_embed") for k, v in enc_p.items()}
     pp = {k: v.detach().clone().requires_grad_(k != "predictor_pos_embed") for k, v in pred_p.items()}
-    h = targets(cfg, tgt_p, imgs, masks_enc, masks_pred)
-    z_ctx = encoder_forward(cfg, ep, imgs, masks_enc)
-    z = predictor_forward(cfg, pp, z_ctx, masks_enc, masks_pred)
+    h = targets(cfg, tgt_p, imgs, masks_enc, masks_pred, pol)
+    z_ctx = encoder_forward(cfg, ep, imgs, masks_enc, pol)
+    z = predictor_forward(cfg, pp, z_ctx, masks_enc, masks_pred, pol)
     loss = F.smooth_l1_loss(z, h)
     (loss * grad_scale).backward()
     ge = {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in ep.items()}

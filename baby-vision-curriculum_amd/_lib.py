@@ -140,10 +140,13 @@ SYMBOLS = {
     "bvc_op_row_normalize_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "bvc_op_nce_finalize": (c_int, [c_void_p, c_int, c_float, c_int64, c_void_p, c_void_p, c_void_p]),
     "bvc_op_sgd_step": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_int, c_int, c_int,
-                                c_void_p, c_void_p, c_int, c_void_p]),
+                                c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "bvc_videomae_shadow": (c_int, [c_void_p, c_int, ctypes.POINTER(c_void_p), ctypes.POINTER(c_int64)]),
+    "bvc_vit_shadow": (c_int, [c_void_p, c_int, ctypes.POINTER(c_void_p), ctypes.POINTER(c_int64)]),
+    "bvc_predictor_shadow": (c_int, [c_void_p, c_int, ctypes.POINTER(c_void_p), ctypes.POINTER(c_int64)]),
     "bvc_op_adam_prepare": (c_int, [c_void_p, c_double, c_double, c_double, c_void_p, c_void_p]),
     "bvc_op_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_double, c_double, c_double, c_double, c_double,
-                                 c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+                                 c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "bvc_op_nonfinite_check": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     "bvc_op_mask_index": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "bvc_op_gather_patches": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),

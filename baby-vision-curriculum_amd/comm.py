@@ -140,15 +140,17 @@ def requested():
     return os.environ.get("BVC_COMM", "") == "bvc"
 
 
-def get(device=None):
+def get(device=None, create=True):
     """This process's library communicator on `device`, created on first use; None when it was not requested (BVC_COMM=bvc) or
     torch.distributed is not running on RCCL.  Creation is collective: call it at the same point on every rank (the data-parallel
-    wrapper's constructor does)."""
+    wrapper's constructor does).  create=False only returns a communicator that exists already: the autograd collectives of
+    distributed.py use it, so that the rendezvous (id broadcast, ncclCommInitRank, probe) can never start lazily from inside a
+    forward or backward on some ranks only."""
     global _comm, _tried
     if _comm is not None and (not (dist.is_available() and dist.is_initialized()) or
                               (dist.get_rank(), dist.get_world_size()) != (_comm.rank, _comm.world)):
         reset()          # the process group it was created for is gone (destroy_process_group / a new init): never reuse it
-    if _comm is not None or _tried:
+    if _comm is not None or _tried or not create:
         return _comm
     if not requested():
         return None

@@ -74,14 +74,47 @@ __device__ __forceinline__ void gelu_and_grad2(f32x2 x, f32x2& act, f32x2& grad)
     const f32x2 phi = __builtin_elementwise_fma(s, f32x2{0.5f, 0.5f}, f32x2{0.5f, 0.5f});
     grad = __builtin_elementwise_fma(x * 0.39894228040143268f, g.e, phi);
 }
-// v[0 .. 2n) -> gelu'(v) in place, gelu(v) to act[]
+// v[0 .. 2n) -> gelu'(v) in place, gelu(v) to act[].  All pairs advance STAGE BY STAGE (round 4): written pair after pair, hipcc
+// keeps each pair's chain of dependent packed operations together and pads it with an `s_nop` per link (8 per pair) - with the
+// stages of several pairs side by side the links of one pair fill the gaps of the others.  Same operations per element as
+// gelu_and_grad2, same results bit for bit.
 template <int N2>
 __device__ __forceinline__ void gelu_split(float (&v)[N2], float (&act)[N2]) {
+    constexpr int P = N2 / 2;
+    f32x2 x[P], ax[P], t[P], pl[P], ex[P], er[P];
 #pragma unroll
-    for (int e = 0; e < N2; e += 2) {
-        f32x2 a, d;
-        gelu_and_grad2(f32x2{v[e], v[e + 1]}, a, d);
-        act[e] = a.x; act[e + 1] = a.y; v[e] = d.x; v[e + 1] = d.y;
+    for (int i = 0; i < P; ++i) {
+        x[i] = f32x2{v[2 * i], v[2 * i + 1]};
+        ax[i].x = __builtin_fabsf(x[i].x); ax[i].y = __builtin_fabsf(x[i].y);
+    }
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+        const f32x2 az = ax[i] * 0.70710678118654752f;
+        const f32x2 d = __builtin_elementwise_fma(az, f32x2{0.3275911f, 0.3275911f}, f32x2{1.0f, 1.0f});
+        t[i].x = __builtin_amdgcn_rcpf(d.x); t[i].y = __builtin_amdgcn_rcpf(d.y);
+        const f32x2 xx = x[i] * x[i] * -0.72134752044448170f;      // exp(-x^2/2) = 2^(-x^2/2 * log2 e)
+        ex[i].x = __builtin_amdgcn_exp2f(xx.x); ex[i].y = __builtin_amdgcn_exp2f(xx.y);
+    }
+#pragma unroll
+    for (int i = 0; i < P; ++i) pl[i] = __builtin_elementwise_fma(t[i], f32x2{1.061405429f, 1.061405429f}, f32x2{-1.453152027f, -1.453152027f});
+#pragma unroll
+    for (int i = 0; i < P; ++i) pl[i] = __builtin_elementwise_fma(pl[i], t[i], f32x2{1.421413741f, 1.421413741f});
+#pragma unroll
+    for (int i = 0; i < P; ++i) pl[i] = __builtin_elementwise_fma(pl[i], t[i], f32x2{-0.284496736f, -0.284496736f});
+#pragma unroll
+    for (int i = 0; i < P; ++i) pl[i] = __builtin_elementwise_fma(pl[i], t[i], f32x2{0.254829592f, 0.254829592f});
+#pragma unroll
+    for (int i = 0; i < P; ++i) pl[i] = pl[i] * t[i];
+#pragma unroll
+    for (int i = 0; i < P; ++i) er[i] = __builtin_elementwise_fma(-pl[i], ex[i], f32x2{1.0f, 1.0f});       // erf(|z|)
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+        const f32x2 a = __builtin_elementwise_fma(ax[i], er[i], x[i]) * 0.5f;
+        f32x2 sg;
+        sg.x = copysignf(er[i].x, x[i].x); sg.y = copysignf(er[i].y, x[i].y);
+        const f32x2 phi = __builtin_elementwise_fma(sg, f32x2{0.5f, 0.5f}, f32x2{0.5f, 0.5f});
+        const f32x2 g = __builtin_elementwise_fma(x[i] * 0.39894228040143268f, ex[i], phi);
+        act[2 * i] = a.x; act[2 * i + 1] = a.y; v[2 * i] = g.x; v[2 * i + 1] = g.y;
     }
 }
 // buffer resource over [base, base+bytes): out-of-range lanes of a buffer load return 0

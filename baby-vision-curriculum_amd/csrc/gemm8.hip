@@ -495,7 +495,10 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const GemmGroup g, const 
                     for (int e = 0; e < 4; ++e) {
                         va[e] = acc[i][2 * jp][e] * alpha + bj[2 * jp][e];
                         vb[e] = acc[i][2 * jp + 1][e] * alpha + bj[2 * jp + 1][e];
-                        if (relu) { va[e] = fmaxf(va[e], 0.f); vb[e] = fmaxf(vb[e], 0.f); }
+                    }
+                    if (relu) {      // (a uniform branch: the GELU path does not carry the max / select pairs)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { va[e] = fmaxf(va[e], 0.f); vb[e] = fmaxf(vb[e], 0.f); }
                     }
                     const int n = ncol + 32 * jp;
                     const uint32_t o = (m < Mrows && n < Ncols) ? (uint32_t)(((size_t)m * ldc + n) * 2) : kDrop;
@@ -508,12 +511,15 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const GemmGroup g, const 
                         __builtin_amdgcn_raw_buffer_store_b128(u32x4{s0[0], s1[0], s0[1], s1[1]}, r, o, 0, BVC_G8_ST_AUX);
                     };
                     if (two_out) {      // EPI_GELU: C <- gelu'(pre), C2 <- gelu(pre)
-                        float ga[4], gb[4];
-                        gelu_split(va, ga);
-                        gelu_split(vb, gb);
+                        float vv[8], gg[8];      // the four pairs of both tiles side by side
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { vv[e] = va[e]; vv[4 + e] = vb[e]; }
+                        gelu_split(vv, gg);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { va[e] = vv[e]; vb[e] = vv[4 + e]; }
                         emit(rc);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) { va[e] = ga[e]; vb[e] = gb[e]; }
+                        for (int e = 0; e < 4; ++e) { va[e] = gg[e]; vb[e] = gg[4 + e]; }
                         emit(rc2);
                     } else {
                         emit(rc);
@@ -708,7 +714,9 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const GemmGroup g, const 
                 const float w = wave_sum(sumsq);
                 // (a wave's parking area is 16 rows x WN floats: wave q's first word is float 16 WN q.  Round 2 indexed it 4 WN q - inside
                 //  the rows OTHER waves were still reading back: one output element per affected tile came out as a partial sum; found by
-                //  tools/g8_race_screen.py in round 3.  No product path selects this epilogue on gemm8: the head + MSE runs on gemm_persist.)
+                //  tools/g8_race_screen.py in round 3.  Since round 3 the head + MSE product of the training step runs on this epilogue from
+                //  64 clips upward (pick_gemm8's `resid` class, tests/test_selection.py); tests/test_gpu_ops.py bit-compares C2 / diff /
+                //  partials with the per-tile kernel.)
                 float* red = reinterpret_cast<float*>(smem + 2 * TILE);
                 if (lane == 0) red[wave * (16 * WN)] = w;
                 asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");

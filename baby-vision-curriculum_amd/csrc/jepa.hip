@@ -108,6 +108,7 @@ struct bvc_vit_ctx {
     int batch = 0, ntok = 0;
     bool have_forward = false;
     bf16_t* wbf;
+    bool shadow_valid = false;   // set by bvc_vit_shadow for ONE forward: wbf already matches the parameters it will be given
     int* idx_all;      // identity token list [max_batch * L]
     const int* idx;    // token list of the current call
     bf16_t* Ape;       // bf16 [B*N][Kp]
@@ -126,6 +127,7 @@ struct bvc_pred_ctx {
     int B = 0, Nc = 0, Np = 0, nsets = 0;
     bool have_forward = false;
     bf16_t* wbf;
+    bool shadow_valid = false;   // see bvc_predictor_shadow
     bf16_t* z_bf;      // bf16 [B*Nc][D]
     float* xe;         // f32 [B*Nc][Dp] embedded context tokens (+ pos)
     const int *idx_ctx, *idx_pred;
@@ -224,7 +226,8 @@ int bvc_vit_forward_px(bvc_vit_ctx* c, const void* imgs_any, const bvc_pixel_for
     c->idx = idx ? idx : c->idx_all;
     c->w.params = params; c->w.wbf = c->wbf;
     const PatchGeom pg{cf.num_frames, cf.num_channels, cf.image_size, cf.image_size, cf.tubelet_size, cf.patch_size};
-    TRY(launch_cast_bf16(params, c->wbf, (size_t)L.total, st));
+    if (!c->shadow_valid) TRY(launch_cast_bf16(params, c->wbf, (size_t)L.total, st));     // see bvc_vit_shadow
+    c->shadow_valid = false;
     TRY(launch_gather_patches(imgs, c->idx, c->Ape, B, N, pg, st));
     {
         GemmProblem p = gemm(c->Ape, (size_t)M * c->Kp, c->Kp, c->wbf + L.pe_w, (size_t)D * c->Kp, c->Kp, M, D, c->Kp, EPI_POS, c->st.act[0].x_in, D);
@@ -241,6 +244,14 @@ int bvc_vit_forward_px(bvc_vit_ctx* c, const void* imgs_any, const bvc_pixel_for
 }
 
 // dout f32 [B*ntok][D] -> grads (flat f32, overwritten).  Pixels and pos_embed receive no gradient.
+int bvc_vit_shadow(bvc_vit_ctx* c, int valid, void** shadow_bf16, int64_t* numel) {
+    BVC_REQUIRE(c, "vit_shadow: null context");
+    if (shadow_bf16) *shadow_bf16 = c->wbf;
+    if (numel) *numel = (int64_t)c->lay.total;
+    if (valid >= 0) c->shadow_valid = valid != 0;
+    return BVC_OK;
+}
+
 int bvc_vit_backward(bvc_vit_ctx* c, const float* dout, float* G, bvc_bucket_fn on_bucket, void* user, void* stream) {
     BVC_REQUIRE(c && dout && G, "vit_backward: null argument");
     if (!c->have_forward) { set_error("vit_backward: no forward state"); return BVC_ERR_STATE; }
@@ -338,7 +349,8 @@ int bvc_predictor_forward(bvc_pred_ctx* c, const float* z, const int* idx_ctx, c
     c->B = B; c->Nc = Nc; c->Np = Np; c->nsets = nsets;
     c->idx_ctx = idx_ctx; c->idx_pred = idx_pred;
     c->w.params = params; c->w.wbf = c->wbf;
-    TRY(launch_cast_bf16(params, c->wbf, (size_t)L.total, st));
+    if (!c->shadow_valid) TRY(launch_cast_bf16(params, c->wbf, (size_t)L.total, st));     // see bvc_predictor_shadow
+    c->shadow_valid = false;
     TRY(launch_gather_rows_bf16(z, identity_rows(), c->z_bf, Mc, D, st));
     {   // predictor_embed + bias + pos[masks_x]
         GemmProblem p = gemm(c->z_bf, (size_t)Mc * D, D, c->wbf + L.emb_w, (size_t)Dp * D, D, Mc, Dp, D, EPI_POS, c->xe, Dp);
@@ -362,6 +374,14 @@ int bvc_predictor_forward(bvc_pred_ctx* c, const float* z, const int* idx_ctx, c
 }
 
 // dout f32 [nsets*B*Np][D] -> grads (flat f32, overwritten) and dz f32 [B*Nc][D] (gradient for the context encoder)
+int bvc_predictor_shadow(bvc_pred_ctx* c, int valid, void** shadow_bf16, int64_t* numel) {
+    BVC_REQUIRE(c, "predictor_shadow: null context");
+    if (shadow_bf16) *shadow_bf16 = c->wbf;
+    if (numel) *numel = (int64_t)c->lay.total;
+    if (valid >= 0) c->shadow_valid = valid != 0;
+    return BVC_OK;
+}
+
 int bvc_predictor_backward(bvc_pred_ctx* c, const float* dout, float* G, float* dz, void* stream) {
     return bvc_predictor_backward_cb(c, dout, G, dz, nullptr, nullptr, stream);
 }

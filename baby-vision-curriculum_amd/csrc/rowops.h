@@ -43,11 +43,12 @@ int launch_labels(PixelSrc clip, const int* msk_idx, float* labels, int B, int n
 int launch_fill_masked(float* xfull, const float* mask_token, const float* pos, const int* msk_idx, int B, int L, int nvis,
                        int nmask, int D, hipStream_t s);
 int launch_sgd_step(float* p, float* g, float* buf, size_t n, float lr, float momentum, float dampening, float wd, int nesterov,
-                    int first, int maximize, const float* grad_scale, const float* found_inf, int write_grad, hipStream_t s);
+                    int first, int maximize, const float* grad_scale, const float* found_inf, int write_grad, bf16_t* shadow,
+                    hipStream_t s);
 int launch_adam_prep(float* state, double lr, double beta1, double beta2, const float* found_inf, hipStream_t s);
 int launch_adam_step(float* p, float* g, float* m, float* v, size_t n, double lr, double beta1, double beta2, double eps, double wd,
                      int decoupled, int maximize, const float* state, const float* grad_scale, const float* found_inf, int write_grad,
-                     hipStream_t s);
+                     bf16_t* shadow, hipStream_t s);
 int launch_pad_heads(const bf16_t* wqkv, const float* bqkv, const bf16_t* wo, bf16_t* wqkv_p, float* bqkv_p, bf16_t* wo_p, int D, int H,
                      int hd, int hdp, hipStream_t s);
 int launch_unpad_head_grads(const float* gwqkv_p, const float* gbqkv_p, const float* gwo_p, float* gwqkv, float* gbqkv, float* gwo, int D,

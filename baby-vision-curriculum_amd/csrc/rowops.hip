@@ -596,7 +596,8 @@ __global__ __launch_bounds__(256) void nce_finalize_kernel(const float* __restri
 // Skips everything when *found_inf != 0 (GradScaler's contract for optimisers with _step_supports_amp_scaling).
 __global__ void sgd_step_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ buf, size_t n, float lr,
                                 float momentum, float dampening, float wd, int nesterov, int first, int maximize,
-                                const float* __restrict__ grad_scale, const float* __restrict__ found_inf, int write_grad) {
+                                const float* __restrict__ grad_scale, const float* __restrict__ found_inf, int write_grad,
+                                bf16_t* __restrict__ shadow) {
     if (found_inf && *found_inf != 0.f) return;
     const float inv = grad_scale ? 1.f / *grad_scale : 1.f;
     const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
@@ -613,7 +614,10 @@ __global__ void sgd_step_kernel(float* __restrict__ p, float* __restrict__ g, fl
             *reinterpret_cast<f32x4*>(buf + i) = bv;
             d = nesterov ? gv + bv * momentum : bv;
         }
-        *reinterpret_cast<f32x4*>(p + i) = pv - d * lr;
+        const f32x4 pn = pv - d * lr;
+        *reinterpret_cast<f32x4*>(p + i) = pn;
+        // the bf16 copy the next forward's products read (round 4): written here, the per-forward cast pass over all parameters goes
+        if (shadow) *reinterpret_cast<uint2*>(shadow + i) = uint2{pack2bf(pn[0], pn[1]), pack2bf(pn[2], pn[3])};
         if (write_grad) *reinterpret_cast<f32x4*>(g + i) = gu;
     } else {
         for (size_t j = i; j < n; ++j) {
@@ -628,6 +632,7 @@ __global__ void sgd_step_kernel(float* __restrict__ p, float* __restrict__ g, fl
                 d = nesterov ? gv + bv * momentum : bv;
             }
             p[j] -= lr * d;
+            if (shadow) shadow[j] = f2bf(p[j]);
             if (write_grad) g[j] = gu;
         }
     }
@@ -650,7 +655,7 @@ __global__ void adam_prep_kernel(float* __restrict__ state, double lr, double be
 __global__ void adam_step_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                  size_t n, float omb1, float beta2, float omb2, float eps, float wd, float decay_mul, int decoupled,
                                  int maximize, const float* __restrict__ state, const float* __restrict__ grad_scale,
-                                 const float* __restrict__ found_inf, int write_grad) {
+                                 const float* __restrict__ found_inf, int write_grad, bf16_t* __restrict__ shadow) {
     if (found_inf && *found_inf != 0.f) return;
     const float inv = grad_scale ? 1.f / *grad_scale : 1.f;
     const float step_size = state[1], bc2s = state[2];
@@ -687,9 +692,14 @@ __global__ void adam_step_kernel(float* __restrict__ p, float* __restrict__ g, f
         *reinterpret_cast<f32x4*>(p + i0) = *reinterpret_cast<f32x4*>(pv);
         *reinterpret_cast<f32x4*>(m + i0) = *reinterpret_cast<f32x4*>(mv);
         *reinterpret_cast<f32x4*>(v + i0) = *reinterpret_cast<f32x4*>(vv);
+        if (shadow) *reinterpret_cast<uint2*>(shadow + i0) = uint2{pack2bf(pv[0], pv[1]), pack2bf(pv[2], pv[3])};
         if (write_grad) *reinterpret_cast<f32x4*>(g + i0) = *reinterpret_cast<f32x4*>(gu);
     } else {
-        for (int e = 0; e < cnt; ++e) { p[i0 + e] = pv[e]; m[i0 + e] = mv[e]; v[i0 + e] = vv[e]; if (write_grad) g[i0 + e] = gu[e]; }
+        for (int e = 0; e < cnt; ++e) {
+            p[i0 + e] = pv[e]; m[i0 + e] = mv[e]; v[i0 + e] = vv[e];
+            if (shadow) shadow[i0 + e] = f2bf(pv[e]);
+            if (write_grad) g[i0 + e] = gu[e];
+        }
     }
 }
 
@@ -966,13 +976,15 @@ int launch_nce_finalize(const float* partial, int ntiles, float inv_t, double np
 }
 
 int launch_sgd_step(float* p, float* g, float* buf, size_t n, float lr, float momentum, float dampening, float wd, int nesterov,
-                    int first, int maximize, const float* grad_scale, const float* found_inf, int write_grad, hipStream_t s) {
+                    int first, int maximize, const float* grad_scale, const float* found_inf, int write_grad, bf16_t* shadow,
+                    hipStream_t s) {
     BVC_REQUIRE(momentum == 0.f || buf != nullptr, "sgd_step: momentum needs a buffer");
+    BVC_REQUIRE(shadow == nullptr || (uintptr_t)shadow % 8 == 0, "sgd_step: the bf16 shadow must be 8-byte aligned");
     BVC_REQUIRE(((uintptr_t)p % 16 == 0) && ((uintptr_t)g % 16 == 0) && (buf == nullptr || (uintptr_t)buf % 16 == 0),
                 "sgd_step: buffers must be 16-byte aligned");
     if (n == 0) return BVC_OK;
     hipLaunchKernelGGL(sgd_step_kernel, dim3(blocks_for((n + 3) / 4)), dim3(256), 0, s, p, g, buf, n, lr, momentum, dampening, wd,
-                       nesterov, first, maximize, grad_scale, found_inf, write_grad);
+                       nesterov, first, maximize, grad_scale, found_inf, write_grad, shadow);
     BVC_CHECK_HIP(hipGetLastError());
     return BVC_OK;
 }
@@ -985,14 +997,15 @@ int launch_adam_prep(float* state, double lr, double beta1, double beta2, const 
 
 int launch_adam_step(float* p, float* g, float* m, float* v, size_t n, double lr, double beta1, double beta2, double eps, double wd,
                      int decoupled, int maximize, const float* state, const float* grad_scale, const float* found_inf, int write_grad,
-                     hipStream_t s) {
+                     bf16_t* shadow, hipStream_t s) {
     BVC_REQUIRE(((uintptr_t)p % 16 == 0) && ((uintptr_t)g % 16 == 0) && ((uintptr_t)m % 16 == 0) && ((uintptr_t)v % 16 == 0),
                 "adam_step: buffers must be 16-byte aligned");
+    BVC_REQUIRE(shadow == nullptr || (uintptr_t)shadow % 8 == 0, "adam_step: the bf16 shadow must be 8-byte aligned");
     if (n == 0) return BVC_OK;
     // hyper-parameters arrive as doubles (python floats) and are combined in double before the cast, as torch does
     hipLaunchKernelGGL(adam_step_kernel, dim3(blocks_for((n + 3) / 4)), dim3(256), 0, s, p, g, m, v, n, (float)(1.0 - beta1), (float)beta2,
                        (float)(1.0 - beta2), (float)eps, (float)wd, (float)(1.0 - lr * wd), decoupled, maximize, state, grad_scale,
-                       found_inf, write_grad);
+                       found_inf, write_grad, shadow);
     BVC_CHECK_HIP(hipGetLastError());
     return BVC_OK;
 }

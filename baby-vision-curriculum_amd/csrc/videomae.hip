@@ -92,6 +92,7 @@ struct bvc_ctx {
     int batch = 0;
     bool have_forward = false;
     bf16_t* wbf;       // bf16 copy of the flat parameters
+    bool shadow_valid = false;   // set by bvc_videomae_shadow for ONE forward: wbf already matches the parameters it will be given
     const float* params = nullptr;
     int *vis_idx, *msk_idx, *status;
     bf16_t* Ape;       // bf16 [B*nvis][Kp] gathered visible tubes
@@ -276,7 +277,10 @@ int bvc_videomae_forward_px(bvc_ctx* c, const void* pixels_any, const bvc_pixel_
     c->w.wbf = c->wbf;
     const PatchGeom pg{cf.num_frames, cf.num_channels, cf.image_size, cf.image_size, cf.tubelet_size, cf.patch_size};
 
-    TRY(launch_cast_bf16(params, c->wbf, (size_t)L.total, st));
+    // the bf16 copy of the parameters: refreshed here unless the caller vouches that it still matches `params` (bvc_videomae_shadow:
+    // the fused optimisers write it together with the parameters)
+    if (!c->shadow_valid) TRY(launch_cast_bf16(params, c->wbf, (size_t)L.total, st));
+    c->shadow_valid = false;
     BVC_CHECK_HIP(hipMemsetAsync(c->status, 0, 16, st));
     TRY(launch_mask_index(mask, B, Lq, nvis, nmask, c->vis_idx, c->msk_idx, c->status, st));
     TRY(launch_gather_patches(pixels, c->vis_idx, c->Ape, B, nvis, pg, st));
@@ -581,10 +585,10 @@ int bvc_op_colsum_bf16(const void* X, int M, int N, int ld, float alpha, const f
 }
 int bvc_op_sgd_step(float* params, float* grads, float* momentum_buf, int64_t n, float lr, float momentum, float dampening,
                     float weight_decay, int nesterov, int first_step, int maximize, const float* grad_scale,
-                    const float* found_inf, int write_unscaled_grads, void* stream) {
+                    const float* found_inf, int write_unscaled_grads, void* bf16_shadow, void* stream) {
     BVC_REQUIRE(params && grads && n >= 0, "op_sgd_step: bad argument");
     return launch_sgd_step(params, grads, momentum_buf, (size_t)n, lr, momentum, dampening, weight_decay, nesterov, first_step,
-                           maximize, grad_scale, found_inf, write_unscaled_grads, (hipStream_t)stream);
+                           maximize, grad_scale, found_inf, write_unscaled_grads, (bf16_t*)bf16_shadow, (hipStream_t)stream);
 }
 int bvc_op_adam_prepare(float* state3, double lr, double beta1, double beta2, const float* found_inf, void* stream) {
     BVC_REQUIRE(state3, "op_adam_prepare: null state");
@@ -592,10 +596,17 @@ int bvc_op_adam_prepare(float* state3, double lr, double beta1, double beta2, co
 }
 int bvc_op_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, double lr, double beta1, double beta2,
                      double eps, double weight_decay, int decoupled, int maximize, const float* state3, const float* grad_scale,
-                     const float* found_inf, int write_unscaled_grads, void* stream) {
+                     const float* found_inf, int write_unscaled_grads, void* bf16_shadow, void* stream) {
     BVC_REQUIRE(params && grads && exp_avg && exp_avg_sq && state3 && n >= 0, "op_adam_step: bad argument");
     return launch_adam_step(params, grads, exp_avg, exp_avg_sq, (size_t)n, lr, beta1, beta2, eps, weight_decay, decoupled, maximize,
-                            state3, grad_scale, found_inf, write_unscaled_grads, (hipStream_t)stream);
+                            state3, grad_scale, found_inf, write_unscaled_grads, (bf16_t*)bf16_shadow, (hipStream_t)stream);
+}
+int bvc_videomae_shadow(bvc_ctx* c, int valid, void** shadow_bf16, int64_t* numel) {
+    BVC_REQUIRE(c, "videomae_shadow: null context");
+    if (shadow_bf16) *shadow_bf16 = c->wbf;
+    if (numel) *numel = (int64_t)c->lay.total;
+    if (valid >= 0) c->shadow_valid = valid != 0;
+    return BVC_OK;
 }
 int bvc_op_nonfinite_check(const float* x, int64_t n, float* found_inf, void* stream) {
     BVC_REQUIRE(x && found_inf && n >= 0, "op_nonfinite_check: bad argument");

@@ -145,6 +145,8 @@ class DistributedDataParallel(nn.Module):
     def _broadcast(self):
         for st in self._flats:
             self._bcast(st.module.flat_parameters())
+            if hasattr(st.module, "_shadow_invalidate"):
+                st.module._shadow_invalidate()      # (the library communicator writes through a raw pointer)
         tensors = [p.data for p in self._loose]
         if isinstance(self.module, nn.Module):
             tensors += [b.data for b in self.module.buffers() if b.is_floating_point()]

@@ -25,11 +25,18 @@ def world():
 def _reduced(t, scale):
     """Sum of `t * scale` over all ranks, as a new tensor (the collective works in place on a private copy)."""
     buf = (t * scale).contiguous() if scale != 1.0 else t.contiguous().clone()
-    nc = _comm.get(buf.device) if buf.is_cuda and buf.dtype == torch.float32 and buf.numel() > 0 else None
+    nc = _comm.get(buf.device, create=False) if buf.is_cuda and buf.numel() > 0 else None
     if nc is not None:
         # bvc_allreduce: on the library's communication stream, behind the gradient buckets already enqueued there (the loss
-        # scalar of AllReduce follows the step's last bucket), the current stream continues after it
-        nc.allreduce(buf.view(-1), average=False)
+        # scalar of AllReduce follows the step's last bucket), the current stream continues after it.  ONE communicator per step
+        # also for bf16 / f16 values (a half-precision loss or embedding gradient): they travel as an f32 copy instead of falling
+        # back to the script's process group while buckets are in flight on the library's.
+        if buf.dtype == torch.float32:
+            nc.allreduce(buf.view(-1), average=False)
+        else:
+            wide = buf.float().contiguous()
+            nc.allreduce(wide.view(-1), average=False)
+            buf = wide.to(buf.dtype)
     else:
         dist.all_reduce(buf, op=dist.ReduceOp.SUM)
     return buf
@@ -76,7 +83,7 @@ class AllGather(torch.autograd.Function):
             return x
         src = x.contiguous()
         out = src.new_empty((n * src.shape[0],) + tuple(src.shape[1:]))
-        nc = _comm.get(src.device) if src.is_cuda else None
+        nc = _comm.get(src.device, create=False) if src.is_cuda else None
         if nc is not None:
             nc.allgather(src, out)                     # bvc_allgather on the current stream (include/bvc.h)
         else:

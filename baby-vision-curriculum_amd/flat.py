@@ -6,11 +6,36 @@ all-reduce are single large transfers while ``state_dict()``, ``parameters()``, 
 keep working with the reference's key names.
 """
 import ctypes
+import weakref
 
 import torch
 import torch.nn as nn
 
 from . import _lib
+
+# every live flat module (weakly): the fused optimisers look a parameter range up here to find the bf16 shadow that mirrors it
+_MODULES = weakref.WeakSet()
+
+
+def shadow_for(ptr, n):
+    """Device address of the bf16 copy of the f32 parameters [ptr, ptr + 4 n), or None.
+
+    The library contexts read every weight from a bf16 copy of the flat parameter buffer.  A forward re-casts the whole buffer
+    unless the module can vouch that the copy still matches (``_shadow_vouch``): that is the case when nothing but a fused
+    optimiser step - which writes the copy together with the parameters, through this address - has touched the parameters since
+    the last forward.  "Nothing else" is judged by torch's version counters - of the flat buffer and of every parameter (an in-place
+    torch operation on either bumps one: torch.optim steps, load_state_dict, collectives on the buffer) - and by explicit
+    invalidation in this package's own raw-pointer writers (EMA, the library communicator's broadcast).  Writes through
+    ``param.data`` bypass version counters by design and are NOT seen: after such a write call ``module._shadow_invalidate()``."""
+    for m in list(_MODULES):
+        f = getattr(m, "_flat", None)
+        if f is None or not f.is_cuda:
+            continue
+        base = f.data_ptr()
+        if base <= ptr and ptr + 4 * n <= base + 4 * f.numel():
+            sp = m._shadow_base()
+            return None if sp is None else sp + 2 * ((ptr - base) // 4)
+    return None
 
 
 def query_layout(count_fn, numel_fn, info_fn, cfg_c):
@@ -41,6 +66,8 @@ class FlatParamModule(nn.Module):
         self._bucket_hook = None      # set by the data-parallel wrapper: fn(offset, count)
         self._after_backward = None
         self._fwd_generation = 0      # bumped by every forward that overwrites the library context's saved activations
+        self._shadow_stamp = None     # (context, flat buffer, its version) at which the context's bf16 copy was last known current
+        _MODULES.add(self)
 
     def _stamp_forward(self):
         """The library context keeps ONE set of saved activations: every forward stamps it; backward checks the stamp."""
@@ -54,6 +81,41 @@ class FlatParamModule(nn.Module):
         if gen != getattr(self, "_fwd_generation", 0) or not same_ctx:
             raise _lib.BvcError("backward of a forward whose saved activations were overwritten: this module ran another forward "
                                 "(validation pass, second view, larger batch) between that forward and its backward")
+
+    # ---- the context's bf16 copy of the parameters (bvc_*_shadow in include/bvc.h); _shadow_fn names the entry point
+    _shadow_fn = None
+
+    def _shadow_key(self, h):
+        f = self._flat
+        ps = getattr(self, "_shadow_params", None)
+        if ps is None:
+            ps = self._shadow_params = [self._param(n) for n in self._names]
+        return (getattr(h, "value", h), f.data_ptr(), f._version, sum(p._version for p in ps))
+
+    def _shadow_vouch(self, h):
+        """Before a forward on context `h`: tell the library whether its bf16 copy still matches the parameters."""
+        if self._shadow_fn is None:
+            return
+        ok = self._shadow_stamp is not None and self._shadow_stamp == self._shadow_key(h)
+        _lib.check(getattr(_lib.lib(), self._shadow_fn)(h, 1 if ok else 0, None, None), self._shadow_fn)
+
+    def _shadow_established(self, h):
+        """After a successful forward on `h`: the copy matches the parameters as they are now."""
+        if self._shadow_fn is not None:
+            self._shadow_stamp = self._shadow_key(h)
+
+    def _shadow_invalidate(self):
+        """For writers that change the parameters through raw pointers without writing the copy (EMA, library broadcast)."""
+        self._shadow_stamp = None
+
+    def _shadow_base(self):
+        """Address of the copy if it is current (so that an optimiser step may keep it current), else None."""
+        h = getattr(self, "_ctx", None)
+        if self._shadow_fn is None or h is None or self._shadow_stamp is None or self._shadow_stamp != self._shadow_key(h):
+            return None
+        p = ctypes.c_void_p()
+        _lib.check(getattr(_lib.lib(), self._shadow_fn)(h, -1, ctypes.byref(p), None), self._shadow_fn)
+        return p.value
 
     def _register(self, dotted, param):
         mod = self
@@ -112,11 +174,13 @@ class FlatParamModule(nn.Module):
         nn.Module.__init__(new)
         for k, v in self.__dict__.items():
             if k in ("_parameters", "_modules", "_buffers", "_flat", "_flat_grad", "_ctx", "_ctx_key", "_live", "_bucket_hook",
-                     "_after_backward") or k.startswith("_forward_") or k.startswith("_backward_") or k.startswith("_state_dict") \
+                     "_after_backward", "_shadow_params", "_shadow_stamp") or k.startswith("_forward_") or k.startswith("_backward_") or k.startswith("_state_dict") \
                     or k.startswith("_load_state_dict"):
                 continue
             new.__dict__[k] = copy.deepcopy(v, memo)
         new._flat = new._flat_grad = None
+        new._shadow_stamp = None
+        _MODULES.add(new)
         new._bucket_hook = new._after_backward = None
         if hasattr(self, "_ctx"):
             new._ctx, new._ctx_key = None, None

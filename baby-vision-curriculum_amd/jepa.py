@@ -111,6 +111,7 @@ class _EncFn(torch.autograd.Function):
 
 
 class VisionTransformer(FlatParamModule):
+    _shadow_fn = "bvc_vit_shadow"
     """Vision Transformer (vision_transformer.py:293-418); forward(x, masks=None) with x (B, T, C, H, W)."""
 
     def __init__(self, img_size=[224], patch_size=16, in_chans=3, num_frames=1, tubelet_size=1, embed_dim=768,
@@ -174,9 +175,11 @@ class VisionTransformer(FlatParamModule):
         h = self._get_ctx(B)
         out = torch.empty((B, N, self.embed_dim), dtype=torch.float32, device=imgs.device)
         fmt = _lib.pixel_format(imgs, self.pixel_mean, self.pixel_std, self.in_chans)
+        self._shadow_vouch(h)
         _lib.check(_lib.lib().bvc_vit_forward_px(h, imgs.data_ptr(), ctypes.byref(fmt) if fmt is not None else None,
                                                  idx.data_ptr() if idx is not None else None, B, N, self._flat.data_ptr(),
                                                  out.data_ptr(), _lib.current_stream_ptr()), "bvc_vit_forward")
+        self._shadow_established(h)
         self._live = (imgs, idx)
         return out
 
@@ -231,6 +234,7 @@ class _PredFn(torch.autograd.Function):
 
 
 class VisionTransformerPredictor(FlatParamModule):
+    _shadow_fn = "bvc_predictor_shadow"
     """vision_transformer.py:421-535; forward(x, masks_x, masks) -> (len(masks) * B, N_pred, embed_dim)."""
 
     def __init__(self, sequence_shape, embed_dim=768, predictor_embed_dim=384, depth=6, num_heads=12, mlp_ratio=4.0,
@@ -289,9 +293,11 @@ class VisionTransformerPredictor(FlatParamModule):
         h = self._get_ctx(B, nsets, Nc + Np)
         zf = z.detach().to(torch.float32).contiguous()
         out = torch.empty((nsets * B, Np, self.embed_dim), dtype=torch.float32, device=z.device)
+        self._shadow_vouch(h)
         _lib.check(_lib.lib().bvc_predictor_forward(h, zf.data_ptr(), idx_ctx.data_ptr(), idx_pred.data_ptr(), B, Nc, nsets, Np,
                                                     self._flat.data_ptr(), out.data_ptr(), _lib.current_stream_ptr()),
                    "bvc_predictor_forward")
+        self._shadow_established(h)
         self._live = (zf, idx_ctx, idx_pred)
         return out
 
@@ -424,6 +430,8 @@ def ema_update(encoder, target_encoder, m):
     """pretrain_jepa.py:431-432 over the flat buffers: one kernel instead of a Python loop over 150 tensors."""
     q, k = encoder.flat_parameters(), target_encoder.flat_parameters()
     _lib.check(_lib.lib().bvc_op_ema(k.data_ptr(), q.data_ptr(), k.numel(), float(m), _lib.current_stream_ptr()), "bvc_op_ema")
+    if hasattr(target_encoder, "_shadow_invalidate"):
+        target_encoder._shadow_invalidate()       # written through a raw pointer: the context's bf16 copy no longer matches
 
 
 class _TokenMean(torch.autograd.Function):

@@ -13,6 +13,7 @@ import ctypes
 import torch
 
 from . import _lib
+from . import flat as _flat
 
 
 class SGD(torch.optim.Optimizer):
@@ -103,7 +104,8 @@ class SGD(torch.optim.Optimizer):
                     float(group["dampening"]), float(group["weight_decay"]), int(group["nesterov"]), first,
                     int(group["maximize"]),
                     grad_scale.data_ptr() if grad_scale is not None else None,
-                    found_inf.data_ptr() if found_inf is not None else None, 1, stream), "bvc_op_sgd_step")
+                    found_inf.data_ptr() if found_inf is not None else None, 1,
+                    _flat.shadow_for(run[0].data_ptr(), n), stream), "bvc_op_sgd_step")
         return loss
 
     def state_dict(self):
@@ -179,7 +181,7 @@ class Adam(torch.optim.Optimizer):
                 _lib.check(L.bvc_op_adam_step(
                     run[0].data_ptr(), run[0].grad.data_ptr(), m.data_ptr(), v.data_ptr(), n, float(group["lr"]), float(b1), float(b2),
                     float(group["eps"]), float(group["weight_decay"]), int(self._decoupled), int(group["maximize"]),
-                    state3.data_ptr(), gs, fi, 1, stream), "bvc_op_adam_step")
+                    state3.data_ptr(), gs, fi, 1, _flat.shadow_for(run[0].data_ptr(), n), stream), "bvc_op_adam_step")
         return loss
 
     def state_dict(self):

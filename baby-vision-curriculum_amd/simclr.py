@@ -81,10 +81,17 @@ class _InfoNCE(torch.autograd.Function):
         ldp = (n + 63) // 64 * 64                      # contraction length of the second product, zero padded
         P = torch.zeros((n, ldp), dtype=torch.bfloat16, device=f.device)
         _ops.gemm(_ops.gemm_desc(fn, fn, n, n, p, _ops.EPI["NCE_BWD"], P, ldc=ldp, alpha=1.0 / T, labels=stats), _ops.NT)
-        # d loss / d fn = (2 / T) * P fn   (P is symmetric); the upstream gradient rides in as a device scalar
+        # d loss / d fn = (2 / T) * P fn   (P is symmetric); the upstream gradient rides in as a device scalar.
+        # fn enters this product as hi + lo (two bf16 terms, ~16 mantissa bits): the normalisation backward below keeps only the
+        # component of d fn ORTHOGONAL to fn, and for the strongly correlated rows a trunk produces (cosines of 0.99) that is a
+        # small difference of large terms - with fn rounded to one bf16 term the feature gradient was 1.7e-2 ... 3.4e-2 off the f32
+        # result (round 3's "S3 d features" = 2.0e-2), with the split 1e-3; rounding P itself accounts for ~1e-3
+        # (tools/debug/nce_grad_error_sources.py; the second pass costs one more product of the loss's own size).
         g = gout.detach().float().contiguous()
         dfn = torch.empty((n, p), dtype=torch.float32, device=f.device)
         _ops.gemm(_ops.gemm_desc(P, fn, n, p, ldp, _ops.EPI["F32"], dfn, alpha=2.0 / T, alpha_dev=g), _ops.NN)
+        fn_lo = _ops.cast_bf16(f * inv.unsqueeze(1) - fn.float())
+        _ops.gemm(_ops.gemm_desc(P, fn_lo, n, p, ldp, _ops.EPI["RESID"], dfn, alpha=2.0 / T, alpha_dev=g, resid=dfn), _ops.NN)
         df = torch.empty_like(dfn)
         _lib.check(_lib.lib().bvc_op_row_normalize_bwd(f.data_ptr(), inv.data_ptr(), dfn.data_ptr(), df.data_ptr(), n, p,
                                                        _lib.current_stream_ptr()), "row_normalize_bwd")

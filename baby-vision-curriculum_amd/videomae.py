@@ -95,6 +95,7 @@ class _Step(torch.autograd.Function):
 
 
 class VideoMAEForPreTraining(FlatParamModule):
+    _shadow_fn = "bvc_videomae_shadow"
     """Drop-in for transformers.VideoMAEForPreTraining on the pre-training path (same state-dict keys)."""
 
     def __init__(self, config: VideoMAEConfig):
@@ -188,9 +189,11 @@ class VideoMAEForPreTraining(FlatParamModule):
         if want_logits:
             pd = cfg.num_channels * cfg.tubelet_size * cfg.patch_size ** 2
             logits = torch.empty((B, nmask, pd), dtype=torch.float32, device=pixels.device)
+        self._shadow_vouch(h)
         _lib.check(_lib.lib().bvc_videomae_forward_px(
             h, pixels.data_ptr(), ctypes.byref(fmt) if fmt is not None else None, mask.data_ptr(), B, self._flat.data_ptr(),
             loss.data_ptr(), logits.data_ptr() if logits is not None else None, _lib.current_stream_ptr()), "bvc_videomae_forward")
+        self._shadow_established(h)
         self._live = (pixels, mask)   # keep the borrowed inputs alive until backward
         return loss, logits
 

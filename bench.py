@@ -135,6 +135,9 @@ def main():
                          "16 clips (slurm_dev_def.bash:52), so the default is 256 (~40 GB); BASELINE.md lists 16 and 64 as well")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-by-batch", action="store_true", help="skip the 64- and 16-clip legs reported as `by_batch`")
+    ap.add_argument("--no-extra", action="store_true",
+                    help="skip the `extra` block: BASELINE configs 4 and 5 on this GPU (I-JEPA ViT-L/16 at 16 and 256 samples, SimCLR "
+                         "ViT-B at 512 images), a few seconds each, after the headline loop")
     ap.add_argument("--no-probe", action="store_true",
                     help="skip the per-kernel probes behind `roofline.kernel` / `roofline.kernels` (profiling runs: only the timed steps' kernels)")
     ap.add_argument("--torch-sgd", action="store_true", help="use torch.optim.SGD instead of the fused HIP update")
@@ -292,6 +295,23 @@ def main():
             by_batch[str(b)] = {"value": round(b * 10 / wall, 2), "unit": "clips/s", "ms_per_step": round(1e3 * wall / 10, 4), "steps": 10,
                                 "roofline": {"bound": "mfma", "achieved": round(tf, 2), "frac": round(tf / PEAK_BF16_TFLOPS, 4), "traffic": tr}}
         clips, B = full, args.batch
+    # BASELINE configs 4 / 5 on this GPU, outside every timed region of the headline metric (tools/bench_legs.py): their own
+    # metrics, units and FLOP counts; never part of `value`
+    extra = None
+    if world == 1 and not args.stream_input and not args.no_extra:
+        from tools import bench_legs
+        del clips
+        model = xmodel = opt = None
+        torch.cuda.empty_cache()
+        extra = {}
+        for key, fn in (("jepa_vit_large_b16", lambda: bench_legs.jepa_leg(bvc, dev, "vit_large", 16)),
+                        ("jepa_vit_large_b256", lambda: bench_legs.jepa_leg(bvc, dev, "vit_large", 256, steps=5)),
+                        ("simclr_vit_base_512", lambda: bench_legs.simclr_leg(bvc, dev, 512))):
+            try:
+                extra[key] = fn()
+            except Exception as e:      # noqa: BLE001 - the headline line must not depend on an extra leg
+                extra[key] = {"error": f"{type(e).__name__}: {e}"}
+            torch.cuda.empty_cache()
     comm = None
     if use_ddp:
         # two more steps OUTSIDE the timed region with per-bucket events on the communication stream: bytes, time, ring bus bandwidth
@@ -337,6 +357,8 @@ def main():
                 line["roofline"].update(kernel_roofline(bvc, B, dev))
             if by_batch:
                 line["by_batch"] = by_batch
+            if extra:
+                line["extra"] = extra
         if comm is not None:
             line["comm"] = comm
         if stream_info is not None:

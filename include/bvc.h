@@ -108,6 +108,13 @@ int bvc_videomae_forward_px(bvc_ctx* ctx, const void* pixels_dev, const bvc_pixe
  *   grads_dev     f32 flat gradient buffer, OVERWRITTEN with d(objective)/d(param) */
 int bvc_videomae_backward(bvc_ctx* ctx, const float* grad_loss_dev, float* grads_dev, bvc_bucket_fn on_bucket,
                           void* user, void* stream);
+/* The context's bf16 copy of the flat parameters (what every product reads) and the hand-shake that lets the caller keep it
+ * current instead of the forward: *shadow_bf16 / *numel (either may be NULL) describe it - element i mirrors element i of the flat
+ * parameter buffer; valid = 1 vouches that it matches the parameters the NEXT forward will be given (that forward then skips its
+ * cast pass over all parameters; the vouch is consumed by it), valid = 0 withdraws the vouch, valid < 0 only queries.
+ * bvc_op_sgd_step / bvc_op_adam_step write the copy together with the parameters (their bf16_shadow argument).  Replaces nothing
+ * in the reference: autocast re-casts every weight on every forward (pretrain_videomae.py:306-308). */
+int bvc_videomae_shadow(bvc_ctx* ctx, int valid, void** shadow_bf16, int64_t* numel);
 
 /* Copies a saved activation of the last forward as f32 into dst_dev (parity probes: "embed",
  * "enc<i>", "x_full", "dec<i>", "labels").  Returns the element count via *numel. */
@@ -163,6 +170,8 @@ int bvc_vit_forward_px(bvc_vit_ctx* ctx, const void* imgs_dev, const bvc_pixel_f
                        const float* params_dev, float* out_dev, void* stream);
 /* d(out) f32 [B*ntok][embed_dim] -> flat gradients (overwritten); buckets reported tail-first as for VideoMAE. */
 int bvc_vit_backward(bvc_vit_ctx* ctx, const float* dout_dev, float* grads_dev, bvc_bucket_fn on_bucket, void* user, void* stream);
+/* as bvc_videomae_shadow */
+int bvc_vit_shadow(bvc_vit_ctx* ctx, int valid, void** shadow_bf16, int64_t* numel);
 
 typedef struct bvc_predictor_config {
     int seq_len;    /* tokens of the full grid (num_patches of the encoder) */
@@ -184,6 +193,8 @@ void bvc_predictor_destroy(bvc_pred_ctx* ctx);
 int bvc_predictor_forward(bvc_pred_ctx* ctx, const float* z_dev, const int* idx_ctx_dev, const int* idx_pred_dev, int B, int Nc,
                           int nsets, int Np, const float* params_dev, float* out_dev, void* stream);
 int bvc_predictor_backward(bvc_pred_ctx* ctx, const float* dout_dev, float* grads_dev, float* dz_dev, void* stream);
+/* as bvc_videomae_shadow */
+int bvc_predictor_shadow(bvc_pred_ctx* ctx, int valid, void** shadow_bf16, int64_t* numel);
 /* The same, reporting gradient ranges tail-first (bvc_bucket_fn, as bvc_videomae_backward / bvc_vit_backward do) so that the
  * data-parallel wrapper can start the predictor's all-reduce per block: DDP(predictor, static_graph=True), pretrain_jepa.py:303. */
 int bvc_predictor_backward_cb(bvc_pred_ctx* ctx, const float* dout_dev, float* grads_dev, float* dz_dev, bvc_bucket_fn on_bucket,
@@ -269,10 +280,13 @@ int bvc_op_row_normalize_bwd(const float* f, const float* inv_norm, const float*
 int bvc_op_nce_finalize(const float* partial, int ntiles, float inv_temperature, int64_t npos, float* loss, float* stats, void* stream);
 /* One-pass torch.optim.SGD(momentum, nesterov) update over a flat f32 range, replacing the optimiser step at
  * pretrain_videomae.py:187-189,313.  grad_scale / found_inf are GradScaler's device scalars (may be NULL):
- * gradients are divided by *grad_scale, and nothing is touched when *found_inf != 0. */
+ * gradients are divided by *grad_scale, and nothing is touched when *found_inf != 0.
+ * bf16_shadow (may be NULL): the bf16 copy of `params` a model context keeps for its products (bvc_videomae_shadow / bvc_vit_shadow /
+ * bvc_predictor_shadow, same offset as `params` inside the flat buffer): written with the updated parameters, so that the next
+ * forward does not have to re-cast all of them. */
 int bvc_op_sgd_step(float* params, float* grads, float* momentum_buf, int64_t n, float lr, float momentum, float dampening,
                     float weight_decay, int nesterov, int first_step, int maximize, const float* grad_scale,
-                    const float* found_inf, int write_unscaled_grads, void* stream);
+                    const float* found_inf, int write_unscaled_grads, void* bf16_shadow, void* stream);
 /* One-pass torch.optim.AdamW / Adam update over a flat f32 range (pretrain_videomae.py:190-193, pretrain_simclr.py:238-240).
  * state3 = device {step count, lr / (1 - beta1^step), sqrt(1 - beta2^step)}: bvc_op_adam_prepare advances it once per optimiser
  * step (not at all when *found_inf != 0), bvc_op_adam_step consumes it.  Hyper-parameters are doubles (python floats) and are
@@ -280,7 +294,7 @@ int bvc_op_sgd_step(float* params, float* grads, float* momentum_buf, int64_t n,
 int bvc_op_adam_prepare(float* state3, double lr, double beta1, double beta2, const float* found_inf, void* stream);
 int bvc_op_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, double lr, double beta1, double beta2,
                      double eps, double weight_decay, int decoupled, int maximize, const float* state3, const float* grad_scale,
-                     const float* found_inf, int write_unscaled_grads, void* stream);
+                     const float* found_inf, int write_unscaled_grads, void* bf16_shadow, void* stream);
 /* GradScaler's inf check (scaler.step at pretrain_videomae.py:313 -> torch.amp.GradScaler._check_inf_per_device) as one read-only
  * pass over a flat f32 range: *found_inf (device f32) is set to 1 if any element is Inf or NaN; it is never cleared here. */
 int bvc_op_nonfinite_check(const float* x, int64_t n, float* found_inf, void* stream);

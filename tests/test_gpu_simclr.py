@@ -34,7 +34,8 @@ def test_info_nce_loss_and_gradient(golden_dir, B, p, seed):
     rel = abs(float(loss) - float(ref)) / abs(float(ref))
     assert rel < 1e-3, (float(loss), float(ref))
     e = G.rel_err(x.grad.cpu(), ref_in.grad)
-    assert e < 2e-2, e
+    G.log_parity(f"[simclr info_nce {2 * B} x {p}] loss rel {rel:.2e}, feature gradient rel L2 {e:.2e} (bar 3e-3)")
+    assert e < 3e-3, e          # round 4: the normalised rows enter the gradient product as hi + lo bf16 terms (was 2e-2)
     fx = json.load(open(os.path.join(golden_dir, "simclr_info_nce.json")))
     for c in fx["cases"]:      # also against the number the reference's own function produced
         if (c["B"], c["p"], c["seed"]) == (B, p, seed):
@@ -343,7 +344,8 @@ def test_simclr_vit_b_gradients_at_64_pairs():
           f"{aggregate(e2e):.2e} (the bound set by conditioning: gates, and 1 / T = 10 on bf16-level feature differences)")
     assert rep["S1 pooled"] < 2e-2 and rep["features end to end"] < 2e-2 and rep["S2 features"] < 2e-2
     assert rep["loss end to end"] < 1e-3 and rep["S3 loss"] < 1e-3
-    assert rep["S3 d features"] < 3e-2 and rep["S4 d pooled"] < 3e-2
+    G.log_parity("[simclr vit_b 64 pairs, staged] " + ", ".join(f"{k} {v:.2e}" for k, v in rep.items()))
+    assert rep["S3 d features"] < 3e-3 and rep["S4 d pooled"] < 3e-2      # S3: the loss's own backward at the device's features (round 3: 2.0e-2)
     over = {k: round(e, 4) for k, e in errs.items() if e >= 3e-2}
     assert not over, over
 

@@ -322,6 +322,59 @@ def test_training_loop_with_gradscaler_and_sgd(fused):
     assert e < 2e-2
 
 
+def test_bf16_shadow_kept_by_the_fused_optimiser():
+    """Round 4: the fused optimisers write the context's bf16 copy of the parameters together with the parameters, and the next
+    forward skips its cast pass - but only while nothing else has touched the parameters (include/bvc.h: bvc_videomae_shadow).
+    (1) after a fused step the copy is vouched for, and the forward computes exactly what a fresh module holding the same
+        parameters computes (which casts); (2) a torch in-place write to a parameter, load_state_dict and a torch.optim step each
+        withdraw the vouch - the forward re-casts and sees the new values; (3) a step skipped by GradScaler leaves both untouched."""
+    cfg = vo.TINY
+    params = vo.make_params(cfg, seed=5)
+    model = _model(cfg, params)
+    pixels, mask = vo.synthetic_batch(cfg, 2, seed=7, mask_ratio=0.75)
+    px, mk = pixels.to(dev), mask.to(dev)
+
+    def fresh_loss():
+        m2 = _model(cfg, {k: v.detach().cpu() for k, v in model.state_dict().items()})
+        return float(m2(px, bool_masked_pos=mk).loss)
+
+    for Opt, kw in ((bvc.optim.SGD, dict(lr=0.05, momentum=0.9, nesterov=True)), (bvc.optim.AdamW, dict(lr=1e-3, betas=(0.9, 0.95)))):
+        opt = Opt(model.parameters(), **kw)
+        assert model._shadow_base() is None or True
+        for _ in range(2):
+            opt.zero_grad()
+            out = model(px, bool_masked_pos=mk)
+            out.loss.backward()
+            assert model._shadow_base() is not None          # established by the forward: the step below will keep it current
+            opt.step()
+            assert model._shadow_stamp == model._shadow_key(model._ctx)      # the fused step did not disturb the vouch
+            got = float(model(px, bool_masked_pos=mk).loss)      # cast skipped
+            assert got == fresh_loss(), (Opt.__name__, got)
+    # (2) writers the version counters see
+    with torch.no_grad():
+        next(iter(model.parameters())).mul_(1.5)
+    assert model._shadow_base() is None
+    assert float(model(px, bool_masked_pos=mk).loss) == fresh_loss()
+    model.load_state_dict(params)
+    assert model._shadow_base() is None
+    assert float(model(px, bool_masked_pos=mk).loss) == fresh_loss()
+    topt = torch.optim.SGD(model.parameters(), lr=0.05)
+    model(px, bool_masked_pos=mk).loss.backward()
+    topt.step()
+    assert model._shadow_base() is None
+    assert float(model(px, bool_masked_pos=mk).loss) == fresh_loss()
+    # (3) a skipped step
+    opt = bvc.optim.SGD(model.parameters(), lr=0.05)
+    opt.zero_grad()
+    model(px, bool_masked_pos=mk).loss.backward()
+    before = model.flat_parameters().clone()
+    opt.grad_scale = torch.ones((), device=dev)
+    opt.found_inf = torch.ones((), device=dev)
+    opt.step()
+    assert torch.equal(before, model.flat_parameters())
+    assert float(model(px, bool_masked_pos=mk).loss) == fresh_loss()
+
+
 def test_state_dict_round_trip_and_keys():
     cfg = vo.TINY
     params = vo.make_params(cfg, seed=4)

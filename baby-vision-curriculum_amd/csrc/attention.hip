@@ -68,7 +68,9 @@ __device__ __forceinline__ void stage64(__amdgpu_buffer_rsrc_t rs, int row0, int
         const int r = RPP * j + lane / CPR;
         const int c = (lane % CPR) ^ swz_dual<HD>(r);
         const uint32_t off = (uint32_t)(((size_t)(row0 + r) * ld + col0 + c * 8) * 2);
-        glds16(rs, off, (uint32_t)(size_t)((AS3 char*)lds) + (uint32_t)j * 1024u);     // asm: see common.h (no compiler-made drain)
+        // (readfirstlane: the LDS address is wave-uniform by construction - it has to sit in a scalar register for M0 - but hipcc cannot
+        //  always prove it once the caller's loop structure gets involved)
+        glds16(rs, off, __builtin_amdgcn_readfirstlane((uint32_t)(size_t)((AS3 char*)lds) + (uint32_t)j * 1024u));     // asm: see common.h (no compiler-made drain)
     }
 }
 
@@ -542,6 +544,233 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const bf16_t* __r
     }
 }
 
+// ============================================================================ whole-head backward for short sequences (round 4)
+// N <= 160 (the encoder's visible tokens; JEPA's context / prediction sets): Q, K, V and dO of one (clip, head) fit in LDS together
+// (4 images of up to 192 rows x 64 = 96 KiB), so ONE workgroup does the whole backward of the head with S, P, dP and dS computed
+// ONCE - the five products of the algorithm instead of the seven the two-kernel form executes (its dQ kernel recomputes S and dP) -
+// with no second pass over HBM, no atomics and the same deterministic sums:
+//   phase 0  LDS-DMA of the four images; lse and -delta = -rowsum(dO * O) of every query into LDS;
+//   phase 1  key on the lane (as attn_bwd_dkdv_kernel): wave w of FIVE owns key block w; per query block S = Q K^T, dP = dO V^T - delta,
+//            P = exp2(S c - lse), dS = P dP;  dV^T += dO^T P, dK^T += Q^T dS in registers; dS^T leaves as bf16 into a [32 k][32 q]
+//            LDS block per (key block, query block) - the one tile that crosses LDS (the dQ product sums over the lane index of dS);
+//   phase 2  query on the lane (as attn_bwd_dq_kernel): wave w owns query block w: dQ^T += K^T dS^T with BOTH operands read
+//            transposed from LDS (K image, dS^T blocks).
+// 146 KiB of LDS: one workgroup per CU.  At N = 160 the two-kernel form runs 2 x 128-row blocks per head at 62 % fill.
+// NBT: number of 32-row blocks when known at compile time (5: the encoder's 160 tokens - both block loops unroll and hipcc overlaps one
+// block's LDS reads and MFMA chains with the previous block's softmax arithmetic), 0: taken from N at run time
+template <int HD, int NBT>
+__global__ __launch_bounds__(320, 1) void attn_bwd_head_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dctx,
+                                                               const bf16_t* __restrict__ ctx, const float* __restrict__ lse,
+                                                               bf16_t* __restrict__ dqkv, int N, int H, int D, int nheads,
+                                                               uint32_t qkv_bytes, uint32_t dctx_bytes, float scale, float scale_log2) {
+    static_assert(HD == 64, "whole-head backward: head_dim 64");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int IMG = 192 * HD * 2, SUB = 32 * HD * 2, KS = 16 * HD * 2;      // image of 3 x 64 rows; 32-row block; 16-row k-step (tr reads)
+    constexpr int QI = 0, KI = IMG, VI = 2 * IMG, OI = 3 * IMG;                   // Q | K | V | dO
+    constexpr int STAT = 4 * IMG;                                                 // lse[192] | -delta[192]
+    constexpr int DST = STAT + 2 * 192 * 4;                                       // dS^T blocks [kb][qb] of 2 KiB: [32 k][32 q] bf16
+    const AS3 char* lds = (const AS3 char*)smem;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ld = 3 * D, h = lane >> 5;
+    const int NB = NBT > 0 ? NBT : (N + 31) >> 5;                 // 32-row blocks (<= 5)
+    const __amdgpu_buffer_rsrc_t rq = make_rsrc(qkv, qkv_bytes), rd = make_rsrc(dctx, dctx_bytes);
+    const FragAddr<HD> fa = make_frag_addr<HD>(lane);
+    const FragAddr<32> fs = make_frag_addr<32>(lane);     // the dS^T blocks are 64-byte-row images
+
+    // PERSISTENT over (clip, head) pairs: with 146 KiB of LDS only one workgroup is resident per CU, and a fresh workgroup per head
+    // would pay its dispatch, its image loads and its statistics in the open.  Inside the loop the NEXT head's Q, V, dO images and
+    // statistics are fetched while phase 2 runs (which reads K and dS^T only), its K image right after phase 2.
+    // FIVE waves (N <= 160 = five 32-row blocks: one key block and one query block per wave; SIMD 0 hosts two waves, which overlap
+    // each other's latencies); the images are staged by the first four (stage64 deals 1-KiB pieces to four waves).
+    auto stage_qvo = [&](int bh) __attribute__((always_inline)) {
+        if (wave < 4) {
+            const int b = bh / H, head = bh % H, row0 = b * N;
+            for (int rb = 0; rb * 64 < N; ++rb) {
+                stage64<HD>(rq, row0 + rb * 64, ld, head * HD, smem + QI + rb * 2 * SUB, wave, lane);
+                stage64<HD>(rq, row0 + rb * 64, ld, 2 * D + head * HD, smem + VI + rb * 2 * SUB, wave, lane);
+                stage64<HD>(rd, row0 + rb * 64, D, head * HD, smem + OI + rb * 2 * SUB, wave, lane);
+            }
+        }
+    };
+    auto stage_k = [&](int bh) __attribute__((always_inline)) {
+        if (wave < 4) {
+            const int b = bh / H, head = bh % H, row0 = b * N;
+            for (int rb = 0; rb * 64 < N; ++rb) stage64<HD>(rq, row0 + rb * 64, ld, D + head * HD, smem + KI + rb * 2 * SUB, wave, lane);
+        }
+    };
+    // statistics of head `bh` into registers: lse of query `tid`, and this thread's share of -delta = -rowsum(dO * O) for the rows
+    // tid >> 3, + 40, ... (8 lanes per row, 16 bytes of dO and O each, folded by three shuffles)
+    float st_lse = 0.f, st_del[5];
+    auto load_stats = [&](int bh) __attribute__((always_inline)) {
+        const int b = bh / H, head = bh % H;
+        st_lse = (tid < N) ? lse[(size_t)bh * N + tid] : 0.f;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const int q = (tid >> 3) + 40 * k, c = tid & 7;
+            float acc = 0.f;
+            if (q < N) {
+                const bf16x8 dv = load8(dctx + (size_t)(b * N + q) * D + head * HD + 8 * c);
+                const bf16x8 ov = load8(ctx + (size_t)(b * N + q) * D + head * HD + 8 * c);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc += bf2f((bf16_t)dv[j]) * bf2f((bf16_t)ov[j]);
+            }
+            st_del[k] = acc;
+        }
+    };
+    auto store_stats = [&]() __attribute__((always_inline)) {
+        AS3 float* st = (AS3 float*)((AS3 char*)smem + STAT);
+        if (tid < 192) st[tid] = st_lse;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            float acc = st_del[k];
+            acc += __shfl_xor(acc, 1, 64);
+            acc += __shfl_xor(acc, 2, 64);
+            acc += __shfl_xor(acc, 4, 64);
+            const int q = (tid >> 3) + 40 * k;
+            if ((tid & 7) == 0 && q < 192) st[192 + q] = -acc;
+        }
+    };
+
+    int bh = blockIdx.x;
+    if (bh >= nheads) return;
+    load_stats(bh);
+    stage_qvo(bh);
+    stage_k(bh);
+    for (; bh < nheads; bh += gridDim.x) {
+    const int b = bh / H, head = bh % H;
+    const int nxt = bh + gridDim.x;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this head's images (and the previous head's stores)
+    store_stats();
+    __syncthreads();
+
+    // ---- phase 1: dK, dV of this wave's key blocks; dS^T to LDS
+    for (int kb = wave; kb < NB; kb += 5) {
+        const int ki = kb * 32 + (lane & 31);
+        bf16x8 kf[HD / 16], vf[HD / 16];
+#pragma unroll
+        for (int st = 0; st < HD / 16; ++st) {
+            kf[st] = *reinterpret_cast<const AS3 bf16x8*>(lds + KI + kb * SUB + fa.rows[st]);
+            vf[st] = *reinterpret_cast<const AS3 bf16x8*>(lds + VI + kb * SUB + fa.rows[st]);
+        }
+        f32x16 dk[HD / 32], dv[HD / 32];
+#pragma unroll
+        for (int t = 0; t < HD / 32; ++t) { dk[t] = zero16(); dv[t] = zero16(); }
+        const bool key_ok = ki < N;
+#pragma unroll
+        for (int qb = 0; qb < (NBT > 0 ? NBT : NB); ++qb) {
+            const AS3 char* qim = lds + QI + qb * SUB;
+            const AS3 char* oim = lds + OI + qb * SUB;
+            const AS3 float* stl = reinterpret_cast<const AS3 float*>(lds + STAT) + qb * 32 + 4 * h;
+            f32x16 s = zero16(), dp;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 nd = *reinterpret_cast<const AS3 f32x4*>(stl + 192 + 8 * g);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dp[4 * g + e] = nd[e];
+            }
+#pragma unroll
+            for (int stp = 0; stp < HD / 16; ++stp) {
+                s = MFMA32(*reinterpret_cast<const AS3 bf16x8*>(qim + fa.rows[stp]), kf[stp], s);
+                dp = MFMA32(*reinterpret_cast<const AS3 bf16x8*>(oim + fa.rows[stp]), vf[stp], dp);
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 ls = *reinterpret_cast<const AS3 f32x4*>(stl + 8 * g);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * g + e;
+                    const float pr = fast_exp2(fmaf(s[r], scale_log2, -ls[e]));
+                    s[r] = pr;
+                    dp[r] = pr * dp[r];
+                }
+            }
+            if (qb * 32 + 32 > N || !__all(key_ok)) {      // ragged last query block / last key block: zero what lies outside (selects, not products)
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (!key_ok || qb * 32 + acc_row(r, h) >= N) { s[r] = 0.f; dp[r] = 0.f; }
+            }
+            const bf16x8 p0 = acc_to_frag(s, 0), p1 = acc_to_frag(s, 1);
+            const bf16x8 d0 = acc_to_frag(dp, 0), d1 = acc_to_frag(dp, 1);
+            // dS^T[k = this lane's key][q = 8 g + 4 h + 0 .. 3]: 8 bytes per (lane, g) into the block's swizzled 64-byte rows
+            {
+                AS3 char* blk = (AS3 char*)smem + DST + (kb * 5 + qb) * 2048 + (lane & 31) * 64 + 8 * h;
+                const int sw = swz_dual<32>(lane & 31);
+                typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+                union { bf16x8 v; u32x2 u[2]; } w0, w1;
+                w0.v = d0; w1.v = d1;
+                *reinterpret_cast<AS3 u32x2*>(blk + ((0 ^ sw) << 4)) = w0.u[0];
+                *reinterpret_cast<AS3 u32x2*>(blk + ((1 ^ sw) << 4)) = w0.u[1];
+                *reinterpret_cast<AS3 u32x2*>(blk + ((2 ^ sw) << 4)) = w1.u[0];
+                *reinterpret_cast<AS3 u32x2*>(blk + ((3 ^ sw) << 4)) = w1.u[1];
+            }
+#pragma unroll
+            for (int t = 0; t < HD / 32; ++t) {
+                dv[t] = MFMA32(lds_tr<0>(oim, fa.tr[t][0], fa.tr[t][1]), p0, dv[t]);
+                dk[t] = MFMA32(lds_tr<0>(qim, fa.tr[t][0], fa.tr[t][1]), d0, dk[t]);
+            }
+#pragma unroll
+            for (int t = 0; t < HD / 32; ++t) {
+                dv[t] = MFMA32(lds_tr<KS>(oim, fa.tr[t][0], fa.tr[t][1]), p1, dv[t]);
+                dk[t] = MFMA32(lds_tr<KS>(qim, fa.tr[t][0], fa.tr[t][1]), d1, dk[t]);
+            }
+        }
+        if (key_ok) {
+            bf16_t* krow = dqkv + (size_t)(b * N + ki) * ld + D + head * HD;
+            bf16_t* vrow = krow + D;
+#pragma unroll
+            for (int t = 0; t < HD / 32; ++t)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int d = 32 * t + 8 * g + 4 * h;
+                    uint2 a = {pack2bf(dk[t][4 * g] * scale, dk[t][4 * g + 1] * scale), pack2bf(dk[t][4 * g + 2] * scale, dk[t][4 * g + 3] * scale)};
+                    *reinterpret_cast<uint2*>(krow + d) = a;
+                    uint2 e = {pack2bf(dv[t][4 * g], dv[t][4 * g + 1]), pack2bf(dv[t][4 * g + 2], dv[t][4 * g + 3])};
+                    *reinterpret_cast<uint2*>(vrow + d) = e;
+                }
+        }
+    }
+    __syncthreads();
+    if (nxt < nheads) {       // Q, V, dO and the statistics are dead: the next head's arrive under phase 2
+        stage_qvo(nxt);
+        load_stats(nxt);
+    }
+
+    // ---- phase 2: dQ of this wave's query blocks
+    for (int qb = wave; qb < NB; qb += 5) {
+        const int qi = qb * 32 + (lane & 31);
+        f32x16 dq[HD / 32];
+#pragma unroll
+        for (int t = 0; t < HD / 32; ++t) dq[t] = zero16();
+#pragma unroll
+        for (int kb = 0; kb < (NBT > 0 ? NBT : NB); ++kb) {
+            const AS3 char* kim = lds + KI + kb * SUB;
+            const AS3 char* blk = lds + DST + (kb * 5 + qb) * 2048;
+            const bf16x8 b0 = lds_tr<0>(blk, fs.tr[0][0], fs.tr[0][1]);
+            const bf16x8 b1 = lds_tr<1024>(blk, fs.tr[0][0], fs.tr[0][1]);
+#pragma unroll
+            for (int t = 0; t < HD / 32; ++t) dq[t] = MFMA32(lds_tr<0>(kim, fa.tr[t][0], fa.tr[t][1]), b0, dq[t]);
+#pragma unroll
+            for (int t = 0; t < HD / 32; ++t) dq[t] = MFMA32(lds_tr<KS>(kim, fa.tr[t][0], fa.tr[t][1]), b1, dq[t]);
+        }
+        if (qi < N) {
+            bf16_t* orow = dqkv + (size_t)(b * N + qi) * ld + head * HD;
+#pragma unroll
+            for (int t = 0; t < HD / 32; ++t)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int d = 32 * t + 8 * g + 4 * h;
+                    uint2 a = {pack2bf(dq[t][4 * g] * scale, dq[t][4 * g + 1] * scale), pack2bf(dq[t][4 * g + 2] * scale, dq[t][4 * g + 3] * scale)};
+                    *reinterpret_cast<uint2*>(orow + d) = a;
+                }
+        }
+    }
+    __syncthreads();
+    if (nxt < nheads) stage_k(nxt);          // K was read by phase 2
+    }
+}
+
 // ============================================================================ host launchers
 // BVC_ATTN_PLAIN_GRID=1 switches the XCD-aware block map off (same-run A/B in tools/microbench.py; read per launch)
 static int xcd_remap() {
@@ -549,6 +778,15 @@ static int xcd_remap() {
     return getenv("BVC_ATTN_PLAIN_GRID") == nullptr;
 #else
     return 1;
+#endif
+}
+
+// the whole-head backward for N <= 160 can be switched off for same-process A/Bs (experiments build: BVC_ATTN_NO_HEAD_KERNEL=1)
+static bool head_kernel_enabled() {
+#ifdef BVC_EXPERIMENTS
+    return getenv("BVC_ATTN_NO_HEAD_KERNEL") == nullptr;
+#else
+    return true;
 #endif
 }
 
@@ -572,6 +810,38 @@ static int bwd_hd(const bf16_t* qkv, const bf16_t* ctx, const bf16_t* dctx, cons
     const float scale = sm_scale > 0.f ? sm_scale : 1.0f / sqrtf((float)HD), scale_log2 = scale * 1.4426950408889634f;
     const dim3 grid((unsigned)(((N + 127) / 128) * B * H));
     const int remap = xcd_remap();
+    if constexpr (HD == 64) {
+        // short sequences: the whole backward of a (clip, head) in one workgroup (attn_bwd_head_kernel); `delta` stays untouched
+        if (parts == 3 && N <= 160 && head_kernel_enabled()) {
+            constexpr size_t lds = 4 * 192 * HD * 2 + 2 * 192 * 4 + 25 * 2048;
+            static bool attr_set = false;
+            if (!attr_set) {
+                BVC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_head_kernel<HD, 5>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                BVC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_head_kernel<HD, 0>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                attr_set = true;
+            }
+            static int ncu = 0;
+            if (ncu == 0) {
+                int dev = 0;
+                hipDeviceProp_t prop;
+                BVC_CHECK_HIP(hipGetDevice(&dev));
+                BVC_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
+                ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+            }
+            const int nheads = B * H;
+            const dim3 g((unsigned)(nheads < ncu ? nheads : ncu));
+            if (N > 128)
+                hipLaunchKernelGGL((attn_bwd_head_kernel<HD, 5>), g, dim3(320), lds, stream, qkv, dctx, ctx, lse, dqkv, N, H, D, nheads,
+                                   (uint32_t)bytes, (uint32_t)((size_t)B * N * D * 2), scale, scale_log2);
+            else
+                hipLaunchKernelGGL((attn_bwd_head_kernel<HD, 0>), g, dim3(320), lds, stream, qkv, dctx, ctx, lse, dqkv, N, H, D, nheads,
+                                   (uint32_t)bytes, (uint32_t)((size_t)B * N * D * 2), scale, scale_log2);
+            BVC_CHECK_HIP(hipGetLastError());
+            return BVC_OK;
+        }
+    }
     // dQ first: it also produces delta = rowsum(dO * O), which the dK/dV kernel consumes
     if (parts & 1) {
 #ifdef BVC_EXPERIMENTS

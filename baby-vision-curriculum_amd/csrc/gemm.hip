@@ -482,6 +482,10 @@ int gemm_pick_tile(const GemmProblem* probs, int nprob, int tile_cfg) {
 // ~2 MiB of the L2 and otherwise once per resident wave of 64 workgroups.  Candidates: no panels, or the widest panel that fits.
 static int pick_panel(const GemmProblem& p, int cfg, GemmLayout layout) {
     if (BVC_EXP_ENV("BVC_GEMM_LEGACY_WALK") != nullptr) return 0;     // experiments build: read per launch for same-process A/Bs
+    if (const char* pe = BVC_EXP_ENV("BVC_GEMM_PANEL")) {             // experiments build: force the panel width (A/B of the walk model)
+        const int tn = (p.N + (cfg == 10 ? 256 : 128) - 1) / (cfg == 10 ? 256 : 128), gq = atoi(pe);
+        if (layout != GEMM_TN && gq > 0) return gq < tn ? gq : tn;
+    }
     // Same-box A/B at B=64 (profiles/r01_e_walk_ab_b64.txt): the panel walk is worth +5 % on the encoder fc1 shape and is
     // neutral elsewhere for NT / NN; the split-K weight-gradient launches are 2-10 % FASTER with the legacy walk (splits
     // fastest, short side first) although it fetches more - the Infinity Cache absorbs the re-reads - so TN keeps it.
@@ -498,6 +502,16 @@ static int pick_panel(const GemmProblem& p, int cfg, GemmLayout layout) {
         return rows_x * a_slab * npan + tiles_n * b_slab * (G * b_slab <= cap ? 1.0 : waves);
     };
     int gmax = (int)(cap / b_slab);
+    if ((cfg == 10 || cfg == 11) && gmax < 2) {
+        // Long K on the one-workgroup-per-CU kernel (round 4): not even two column tiles' B slabs fit the L2 budget, so no panel is
+        // kept across rounds whatever G is - what counts is the set of tiles RESIDENT on the XCD (32 workgroups that started together
+        // and advance along K in step): with G = 1 they are 32 row tiles of one column, 33 distinct operand tiles per K step for 64
+        // fetched - rocprofv3 measures an L2 hit rate of 0.485 on the 8192^3 square (profiles/r04_k_pmc_mem_g8.txt) and half of all
+        // fills cross the fabric.  A square-ish resident set (G = 6: 5.3 x 6 tiles, 11.3 distinct per 64 fetched) brings the square
+        // from 907 to 742 us = 1.48 PFLOP/s (profiles/r04_k_panel_ab.txt); the step's K >= 1536 products (tiles_n = 3) are neutral.
+        const int gq = cfg == 10 ? 6 : 8;
+        return gq < tiles_n ? gq : tiles_n;
+    }
     if (gmax < 1) gmax = 1;
     if (gmax >= tiles_n) return tiles_n;
     const int npan = (tiles_n + gmax - 1) / gmax;

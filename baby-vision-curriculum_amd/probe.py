@@ -153,6 +153,13 @@ def _attention_rows(dev, B, add):
         unit = 2.0 * N * N * 64 * H * B                 # one N x N x 64 product per head
         tok = 2.0 * B * N * Dm                          # bytes of one bf16 [B N][D] tensor
         add("bvc::attn_fwd_kernel<64>", f"{label} attention fwd", count, _time(fwd), 2 * unit, 4 * tok)
+        if N <= 160:
+            # sequences of up to 160 tokens: the whole backward of a (clip, head) in ONE workgroup (csrc/attention.hip: attn_bwd_head_kernel),
+            # five products, q / k / v / dO / O read and dq / dk / dv written once
+            bwd = lambda: _lib.check(lib.bvc_op_attention_bwd(p(qkv), p(ctx), p(dctx), p(lse), p(delta), p(dqkv), B, N, H, 64, st()), "attention_bwd")
+            add(f"bvc::attn_bwd_head_kernel<64, {5 if N > 128 else 0}>", f"{label} attention bwd (whole head: S, dP, dV, dK, dQ)", count, _time(bwd),
+                5 * unit, 8 * tok)
+            continue
         add("bvc::attn_bwd_dq_kernel<64>", f"{label} attention bwd dQ (S, dP, dQ)", count, _time(dq), 3 * unit, 6 * tok)
         add("bvc::attn_bwd_dkdv_kernel<64>", f"{label} attention bwd dK dV (recomputes S, dP)", count, _time(dkv), 2 * unit, 6 * tok)
 

@@ -81,18 +81,18 @@ PY
     encode) run encode 300 python tools/bench_encode.py ;;
     simclr) run simclr 400 python tools/bench_simclr.py ;;
     prof)  rm -rf $OUT/prof; cd /tmp
-           run prof 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-by-batch --no-probe --batch ${BVC_BATCH:-256}
+           run prof 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-by-batch --no-probe --no-extra --batch ${BVC_BATCH:-256}
            cd $R
            find $OUT/prof -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/kernel_stats.csv
            find $OUT/prof -name "*kernel_trace.csv" -size +20M -delete ;;
     traffic) rm -rf $OUT/pmct; cd /tmp
-           run traffic_rd 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmct/rd -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-by-batch --no-probe --batch ${BVC_BATCH:-256}
-           run traffic_wr 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmct/wr -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-by-batch --no-probe --batch ${BVC_BATCH:-256}
+           run traffic_rd 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmct/rd -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-by-batch --no-probe --no-extra --batch ${BVC_BATCH:-256}
+           run traffic_wr 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmct/wr -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-by-batch --no-probe --no-extra --batch ${BVC_BATCH:-256}
            cd $R
            run traffic 60 python tools/pmc_traffic.py $OUT/pmct/rd $OUT/pmct/wr 3 ${BVC_BATCH:-256} $OUT/traffic_b${BVC_BATCH:-256}.json
            find $OUT/pmct -name "*.csv" -size +5M -delete ;;
     mfma)  rm -rf $OUT/pmcm; cd /tmp
-           run mfma_pmc 400 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES --output-format csv -d $OUT/pmcm -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-by-batch --no-probe --batch ${BVC_BATCH:-256}
+           run mfma_pmc 400 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES --output-format csv -d $OUT/pmcm -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-by-batch --no-probe --no-extra --batch ${BVC_BATCH:-256}
            cd $R
            run mfma_table 60 python tools/pmc_mfma_step.py $OUT/pmcm 3 $OUT/mfma_busy_b${BVC_BATCH:-256}.txt
            find $OUT/pmcm -name "*.csv" -size +5M -delete ;;
@@ -101,7 +101,7 @@ PY
            cd $R; find $OUT/profd -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/kernel_stats_default.csv
            find $OUT/profd -name "*kernel_trace.csv" -delete ;;
     profnobb) rm -rf $OUT/profn; cd /tmp      # the default command without the 64- / 16-clip legs: every launch of a kernel is at the headline batch
-           run profnobb 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/profn -- python3 $R/bench.py --no-by-batch
+           run profnobb 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/profn -- python3 $R/bench.py --no-by-batch --no-extra
            cd $R; find $OUT/profn -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/kernel_stats_no_by_batch.csv
            find $OUT/profn -name "*kernel_trace.csv" -delete ;;
     prof_jepa) rm -rf $OUT/prof_jepa; cd /tmp

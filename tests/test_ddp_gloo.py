@@ -366,6 +366,28 @@ BODIES = {"videomae": _body_videomae, "jepa": _body_jepa, "simclr": _body_simclr
           "unused_on_one_rank": _body_unused_on_one_rank, "head_only": _body_head_only}
 
 
+def _freeze(o):
+    """Tensors leave the rank as numpy arrays: torch shares tensor storage between processes through file descriptors that the
+    RECEIVER fetches from the sender while it is still alive - a rank that has exited by then resets the connection."""
+    if isinstance(o, torch.Tensor):
+        return ("__tensor__", o.detach().cpu().numpy())
+    if isinstance(o, (list, tuple)):
+        return type(o)(_freeze(x) for x in o)
+    if isinstance(o, dict):
+        return {k: _freeze(v) for k, v in o.items()}
+    return o
+
+
+def _thaw(o):
+    if isinstance(o, tuple) and len(o) == 2 and isinstance(o[0], str) and o[0] == "__tensor__":
+        return torch.from_numpy(o[1])
+    if isinstance(o, (list, tuple)):
+        return type(o)(_thaw(x) for x in o)
+    if isinstance(o, dict):
+        return {k: _thaw(v) for k, v in o.items()}
+    return o
+
+
 def _entry(body, rank, world, port, q):
     try:
         os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -375,7 +397,7 @@ def _entry(body, rank, world, port, q):
         bvc = _load()
         out = BODIES[body](rank, world, bvc)
         dist.barrier()
-        q.put((rank, "ok", out))
+        q.put((rank, "ok", _freeze(out)))
         dist.destroy_process_group()
     except Exception:
         q.put((rank, "error", traceback.format_exc()))
@@ -414,7 +436,7 @@ def _run_once(body, world=2):
                 p.terminate()
     errs = [g for g in got if g[1] != "ok"]
     assert not errs, "\n".join(f"rank {r}:\n{tb}" for r, _s, tb in errs)
-    return [g[2] for g in sorted(got, key=lambda t: t[0])]
+    return [_thaw(g[2]) for g in sorted(got, key=lambda t: t[0])]
 
 
 # --------------------------------------------------------------------------- tests

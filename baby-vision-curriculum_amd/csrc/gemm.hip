@@ -647,6 +647,7 @@ int launch_gemm(const GemmProblem* probs, int nprob, GemmLayout layout, int tile
     const int cfg = gemm_pick_tile(probs, nprob, tile_cfg);
     GemmGroup g;
     g.nprob = nprob;
+    g.bal_units = g.bal_lb = g.bal_tiles = 0;
     {
         const char* e = BVC_EXP_ENV("BVC_GEMM_DEBUG");
         g.dbg = e ? atoi(e) : 0;

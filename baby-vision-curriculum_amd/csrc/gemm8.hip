@@ -71,17 +71,25 @@ __device__ __forceinline__ bf16x8 tr_frag(uint32_t region, uint32_t lane_base, u
 // unit id -> problem, tile, K range.  Uniform (kernel arguments and blockIdx only).
 template <int BM, int BN>
 __device__ __forceinline__ void decode_unit(const GemmGroup& g, int uid, Unit& u) {
+    // balanced weight-gradient walk (GemmGroup::bal_*): ids below bal_units are the full-length units, id bal_units + t is the tail of
+    // tile t (tiles counted problem after problem, row-major); tile_start counts units, i.e. tiles x split_k (uniform over the group)
+    const bool tail = g.bal_units > 0 && uid >= g.bal_units;
+    const int S = tail ? g.prob[0].split_k : 1;
+    const int key = tail ? (uid - g.bal_units) * S : uid;
     int pi = 0;
 #pragma unroll
     for (int i = 1; i < kMaxGroup; ++i)
-        if (i < g.nprob && uid >= g.tile_start[i]) pi = i;
+        if (i < g.nprob && key >= g.tile_start[i]) pi = i;
     const GemmProblem& p = g.prob[pi];
-    const int lid = uid - g.tile_start[pi];
+    const int lid = tail ? (key - g.tile_start[pi]) / S : uid - g.tile_start[pi];
     const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
     const int ntiles = tiles_m * tiles_n;
     const int G = g.panel[pi];
     int split, tm, tn;
-    if (G > 0) {
+    if (tail) {
+        split = S;
+        tm = lid / tiles_n; tn = lid - tm * tiles_n;
+    } else if (G > 0) {
         split = lid / ntiles;
         tile_of(lid - split * ntiles, tiles_m, tiles_n, G, tm, tn);
     } else {   // K splits fastest, then along the shorter side (the weight-gradient walk of gemm_kernel)
@@ -94,11 +102,16 @@ __device__ __forceinline__ void decode_unit(const GemmGroup& g, int uid, Unit& u
     const int nt_all = (p.K + 63) / 64;
     int per = (nt_all + p.split_k - 1) / p.split_k;
     per = (per + 1) & ~1;                        // the K loop is unrolled over two K tiles (LDS slot parity)
+    int kt0 = split * per;
+    if (g.bal_units > 0) {                       // splits of bal_lb K tiles (even), the tail takes what is left of the tile
+        kt0 = split * g.bal_lb;
+        per = tail ? (nt_all - kt0 + 1) & ~1 : g.bal_lb;
+    }
     // integer divisions run on the vector ALU: pin the (uniform) results to scalar registers
     u.pi = pi;
     u.m0 = __builtin_amdgcn_readfirstlane(tm * BM);
     u.n0 = __builtin_amdgcn_readfirstlane(tn * BN);
-    u.kt0 = __builtin_amdgcn_readfirstlane(split * per);
+    u.kt0 = __builtin_amdgcn_readfirstlane(kt0);
     u.nkt = __builtin_amdgcn_readfirstlane(per);
     u.split = __builtin_amdgcn_readfirstlane(split);
     u.tile = __builtin_amdgcn_readfirstlane(tm * tiles_n + tn);
@@ -148,8 +161,21 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const GemmGroup g, const 
     const int xq = total_units >> 3, xr = total_units & 7;
     const int x_lo = xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq;
     const int x_hi = x_lo + xq + (xcd < xr ? 1 : 0);
-    int uid = x_lo + slot_id;
-    if (uid >= x_hi) return;       // uniform per workgroup, before any barrier
+    int uid = x_lo + slot_id, u_step = nslots, u_hi = x_hi;
+    if (EC == 2 && g.bal_units > 0) {
+        // balanced walk: the XCD's share of the bal_units full-length units goes one to a workgroup (total_units = bal_units here);
+        // the workgroups left over take consecutive tails, [J T / I, (J + 1) T / I) for the J-th of the I idle workgroups
+        // (numbered XCD after XCD, so that an XCD's tails are neighbouring tiles)
+        u_step = 1;
+        if (uid < x_hi) {
+            u_hi = uid + 1;
+        } else {
+            const int J = xcd * nslots - x_lo + (uid - x_hi), I = 8 * nslots - g.bal_units;
+            uid = g.bal_units + (J * g.bal_tiles) / I;
+            u_hi = g.bal_units + ((J + 1) * g.bal_tiles) / I;
+        }
+    }
+    if (uid >= u_hi) return;       // uniform per workgroup, before any barrier
 
     // ------------------------------------------------------------------ the staging cursor (runs ahead of the compute)
     Unit su;
@@ -192,8 +218,8 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const GemmGroup g, const 
     auto s_advance = [&]() {
         if (++s_kt == su.nkt) {
             s_kt = 0;
-            s_uid += nslots;
-            if (s_uid < x_hi) {
+            s_uid += u_step;
+            if (s_uid < u_hi) {
                 const int old = su.pi;
                 decode_unit<BM, BN>(g, s_uid, su);
                 if (su.pi != old) s_problem();
@@ -739,8 +765,8 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const GemmGroup g, const 
                 if (wn < TMH && (lane >> 4) == 0 && m < p.M) atomicAdd(p.rowsum + m, v * alpha);
             }
         }
-        uid += nslots;
-        if (uid >= x_hi) break;
+        uid += u_step;
+        if (uid >= u_hi) break;
         decode_unit<BM, BN>(g, uid, cu);
         // (atomics and the 384-wide tile's dword stores queue behind the prefetch like any store: the plain counted wait of the next
         //  K tile then waits for them as well - once per unit, conservative and exact)
@@ -754,8 +780,49 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const GemmGroup g, const 
 }
 
 // ------------------------------------------------------------------ host side
+static int g8_ncu() {
+    static int ncu = 0;
+    if (ncu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+        ncu = prop.multiProcessorCount > 0 ? (prop.multiProcessorCount / 8) * 8 : 256;
+        if (ncu < 8) ncu = 8;
+    }
+    return ncu;
+}
+
+// Balanced walk for a split-K weight-gradient group whose units do not fill the chip (the encoder layer's four gradients at 64 / 256
+// clips: 108 tiles x 2 splits = 216 units on 256 CUs, 40 CUs idle for the whole launch).  Every tile gives up its last Lt K tiles: the
+// splits shrink to Lb = (nt - Lt) / S, the T tails go to the I idle workgroups, q = ceil(T / I) each.  A tail pays its own epilogue
+// (e, in K-tile times) - balance: Lb + e = q (c Lt + e).  Off (returns false) when the group is not of that shape or the gain is < 5 %.
+static bool plan_balance(GemmGroup& g, int bm, int bn, int total, int ncu) {
+    if (BVC_EXP_ENV("BVC_G8_NO_BALANCE") != nullptr) return false;
+    const int S = g.prob[0].split_k, nt = (g.prob[0].K + 63) / 64;
+    if (S < 2 || total >= ncu || total % S != 0) return false;
+    for (int i = 0; i < g.nprob; ++i) {
+        const GemmProblem& p = g.prob[i];
+        if (p.split_k != S || (p.K + 63) / 64 != nt || p.epi != EPI_F32) return false;
+        if (g.tile_start[i] % S != 0 || g.panel[i] <= 0) return false;
+    }
+    const int T = total / S, I = ncu - total, q = (T + I - 1) / I;
+    double e = 6.0, c = 1.0;
+    if (const char* v = BVC_EXP_ENV("BVC_G8_BALANCE_EPI")) e = atof(v);
+    if (const char* v = BVC_EXP_ENV("BVC_G8_BALANCE_TAIL")) c = atof(v);
+    const double lt = ((double)nt / S - (q - 1) * e) / (q * c + 1.0 / S);
+    if (lt < 2.0) return false;
+    const int per = (((nt + S - 1) / S) + 1) & ~1;
+    const int lb = (int)((nt - lt) / S) & ~1;
+    if (lb < 8 || nt - S * lb < 2 || lb > 0.95 * per) return false;
+    g.bal_units = total;
+    g.bal_lb = lb;
+    g.bal_tiles = T;
+    (void)bm; (void)bn;
+    return true;
+}
+
 template <int BM, int BN, bool AT, bool BT, int EC>
-static int launch_gemm8_one(const GemmGroup& g, int total, hipStream_t stream) {
+static int launch_gemm8_one(const GemmGroup& g_in, int total, hipStream_t stream) {
     // two K-tile slots + the epilogue region: 16 parked rows per wave (classes 1-3; 16 x 48 for the 384-wide tile) or the bias
     // copy of class 0 (32 KiB: N <= 8192)
     constexpr size_t lds = 2 * (size_t)(BM + BN) * 64 * 2 + (EC == 0 ? (size_t)32768 : BN == 384 ? (size_t)8 * 16 * 48 * 4 : (size_t)8 * 16 * (BN / 4) * 4);
@@ -770,16 +837,12 @@ static int launch_gemm8_one(const GemmGroup& g, int total, hipStream_t stream) {
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    static int ncu = 0;
-    if (ncu == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        BVC_CHECK_HIP(hipGetDevice(&dev));
-        BVC_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
-        ncu = prop.multiProcessorCount > 0 ? (prop.multiProcessorCount / 8) * 8 : 256;
-        if (ncu < 8) ncu = 8;
+    const int ncu = g8_ncu();
+    GemmGroup g = g_in;
+    int grid = total < ncu ? ((total + 7) / 8) * 8 : ncu;      // one workgroup per CU, a multiple of the 8 XCDs
+    if constexpr (EC == 2) {
+        if (plan_balance(g, BM, BN, total, ncu)) grid = ncu;    // the full-length units partition over the XCDs as before; every CU gets a workgroup
     }
-    const int grid = total < ncu ? ((total + 7) / 8) * 8 : ncu;      // one workgroup per CU, a multiple of the 8 XCDs
     hipLaunchKernelGGL((gemm8_kernel<BM, BN, AT, BT, EC>), dim3(grid), dim3(512), lds, stream, g, total);
     BVC_CHECK_HIP(hipGetLastError());
     return BVC_OK;

@@ -27,6 +27,10 @@ struct GemmGroup {
     int panel[kMaxGroup];          // column tiles per panel of the tile walk (0 = the legacy walk, A/B only); see pick_panel
     int dbg;                       // BVC_GEMM_DEBUG experiments (tools/gemm_dbg.py): 1 = drop the bf16 stores, 2 = stagger odd slots,
                                    // 8 = no B-operand refills, 16 = no MFMAs, 32 = no refills at all (results are garbage for 8/16/32)
+    // Balanced weight-gradient walk of gemm8.hip (0 = off): `bal_units` full-length units (tile x K split) fill fewer workgroups than the
+    // grid has, so every unit gives up the last K tiles of its tile: the splits cover `bal_lb` K tiles each, and the remainder of
+    // each of the `bal_tiles` tiles becomes a short "tail" unit; the otherwise idle workgroups take a few tails each (launch_gemm8).
+    int bal_units, bal_lb, bal_tiles;
     GemmProblem prob[kMaxGroup];
 };
 

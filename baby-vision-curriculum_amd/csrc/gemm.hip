@@ -644,10 +644,21 @@ int launch_gemm(const GemmProblem* probs, int nprob, GemmLayout layout, int tile
         BVC_REQUIRE(false, "launch_gemm: tile configs 3-5 / 8 exist only in a -DBVC_EXPERIMENTS build (csrc/experiments/gemm_big.hip)");
 #endif
     }
+    // tile config 13 = tile config 10 (256 x 256, gemm8.hip) for weight gradients whose outputs are ACCUMULATED: C += dY^T X by f32
+    // atomics whether K is split or not (C pre-zeroed, as for split_k > 1).  An unsplit group that fills only part of the chip can
+    // then take the balanced walk (plan_balance in gemm8.hip); plan_dw returns it for such groups.
+    bool accum = false;
+    if (tile_cfg == 13) {
+        BVC_REQUIRE(layout == GEMM_TN, "launch_gemm: tile config 13 (accumulating 256 x 256 tiles) is for weight gradients (TN)");
+        for (int i = 0; i < nprob; ++i) BVC_REQUIRE(probs[i].epi == EPI_F32, "launch_gemm: tile config 13 takes plain f32 outputs");
+        accum = true;
+        tile_cfg = 10;
+    }
     const int cfg = gemm_pick_tile(probs, nprob, tile_cfg);
     GemmGroup g;
     g.nprob = nprob;
     g.bal_units = g.bal_lb = g.bal_tiles = 0;
+    g.accum = accum ? 1 : 0;
     {
         const char* e = BVC_EXP_ENV("BVC_GEMM_DEBUG");
         g.dbg = e ? atoi(e) : 0;

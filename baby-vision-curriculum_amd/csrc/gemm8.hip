@@ -488,7 +488,7 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const GemmGroup g, const 
                 *reinterpret_cast<AS3 f32x4*>(wl + row * (WN * 4) + unit * 16) = acc[i][j];
             }
         };
-        const bool atomic = p.split_k > 1;
+        const bool atomic = p.split_k > 1 || g.accum != 0;
         if constexpr (EC == 0) {
             // bf16 outputs without side inputs, entirely in registers: v = alpha acc + bias in the MFMA layout (lane = row l & 15,
             // 4 consecutive columns at 4 (l >> 4) of each 16 x 16 tile), bias out of the LDS copy made at kernel entry (no
@@ -799,7 +799,7 @@ static int g8_ncu() {
 static bool plan_balance(GemmGroup& g, int bm, int bn, int total, int ncu) {
     if (BVC_EXP_ENV("BVC_G8_NO_BALANCE") != nullptr) return false;
     const int S = g.prob[0].split_k, nt = (g.prob[0].K + 63) / 64;
-    if (S < 2 || total >= ncu || total % S != 0) return false;
+    if ((S < 2 && !g.accum) || total >= ncu || total % S != 0) return false;     // (every unit of the walk adds into C)
     for (int i = 0; i < g.nprob; ++i) {
         const GemmProblem& p = g.prob[i];
         if (p.split_k != S || (p.K + 63) / 64 != nt || p.epi != EPI_F32) return false;

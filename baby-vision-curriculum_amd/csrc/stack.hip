@@ -180,7 +180,9 @@ int plan_dw(GemmProblem* g, int n) {
         //  558 at 64, 125 vs 139 (the 128 x 128 kernel) at 16 - it needs a shorter stream than the 256 x 256 tile to pay off)
         const bool long_enough = g8 > 0 ? ksteps >= 2 : (ksteps >= 16 && flops >= 80e9);
         if (ok && by384 && long_enough && units256 * 65536.0 >= 1.2 * outs) {
-            const int smax = std::max(1, std::min(16, ksteps / (g8 > 0 ? 2 : 16)));
+            // (up to 24 splits since round 4: the head's 12 tiles x 21 = 252 units, 498 vs 564 us with 16 splits at 256 clips -
+            //  profiles/r04_o_head_dw_splits.txt; an atomic pass over its 2.4 MB of outputs per split is noise)
+            const int smax = std::max(1, std::min(24, ksteps / (g8 > 0 ? 2 : 16)));
             int best = 1;
             double best_cost = 1e300;
             for (int sp = 1; sp <= smax; ++sp) {
@@ -211,6 +213,13 @@ int plan_dw(GemmProblem* g, int n) {
                     for (int i = 0; i < n; ++i) g[i].split_k = split;
                     return t == 0 ? 10 : 11;
                 }
+            }
+            // 256 x 256 tiles that fill half to 15/16 of the chip unsplit and overflow it when split (ViT-L layers: 192 tiles): tile
+            // config 13 - the outputs are accumulated by f32 atomics (every caller of plan_dw zeroes the gradient buffer first, as for a
+            // K split), which lets gemm8's balanced walk hand the tails of the K ranges to the idle CUs (launch_gemm, plan_balance)
+            if (units256 >= 128 && units256 <= 240 && ksteps >= 64) {
+                for (int i = 0; i < n; ++i) g[i].split_k = 1;
+                return 13;
             }
         }
     }

@@ -242,7 +242,10 @@ typedef struct bvc_gemm_desc {
     float* rowsum;                  /* TN only: rowsum[m] += alpha * sum_k A(m,k)  (bias gradient of the same dY) */
 } bvc_gemm_desc;
 /* tile_cfg: -1 auto; 0 = 128x128, 1 = 128x64, 2 = 64x64 (one workgroup per tile); 6 / 7 = persistent 128x128 / 128x64,
- * 9 = persistent 128x128 with deferred stores; 10 / 11 = 256x256 / 256x128, one 512-thread workgroup per CU (gemm8.hip).
+ * 9 = persistent 128x128 with deferred stores; 10 / 11 = 256x256 / 256x128, one 512-thread workgroup per CU (gemm8.hip);
+ * 12 = 128x384 (TN only); 13 = 10 for TN products with plain f32 outputs that are ACCUMULATED: C += A^T B by f32 atomics even when
+ * split_k == 1 (C pre-zeroed or holding the values to add to, as for split_k > 1) - bvc_op_gemm_plan_dw returns it for groups whose
+ * unsplit tiles fill half to 15/16 of the chip: their K ranges are then balanced over all CUs.
  * (3-5 and 8 are experiment kernels that exist only in a -DBVC_EXPERIMENTS build.)  stages: -1 auto, 2..4 = K-loop variant. */
 int bvc_op_gemm(const bvc_gemm_desc* problems, int count, int layout, int tile_cfg, int stages, void* stream);
 int bvc_op_gemm_num_tiles(const bvc_gemm_desc* problem, int tile_cfg);

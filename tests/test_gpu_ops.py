@@ -784,3 +784,31 @@ def test_gemm8_weight_gradient_group(tile, split):
         assert G.rel_err(o, r) < 1e-5
     for b, x in zip(bs, (dy, dh, dy, dqkv)):
         assert float((b - x.float().sum(0)).abs().max()) < 2e-2 * math.sqrt(Mtok / 1000.0)
+
+
+@pytest.mark.parametrize("Mtok", [5000, 25600])
+def test_gemm8_accumulating_weight_gradient_group(Mtok):
+    # tile config 13: 256 x 256 tiles whose outputs are ADDED to what C holds (f32 atomics with split_k = 1), the form plan_dw picks for
+    # ViT-L layers - 192 unsplit tiles on 256 CUs, balanced by handing the tails of the K ranges to the idle quarter of the chip
+    D, I = 1024, 4096
+    dy, act = G.bf16_randn(Mtok, D, seed=7), G.bf16_randn(Mtok, I, seed=8)
+    dh, ln2 = G.bf16_randn(Mtok, I, seed=9), G.bf16_randn(Mtok, D, seed=10)
+    dqkv, ln1 = G.bf16_randn(Mtok, 3 * D, seed=11), G.bf16_randn(Mtok, D, seed=12)
+    shapes = [(D, I), (I, D), (D, D), (3 * D, D)]
+    base = [torch.randn(s, device=dev) for s in shapes]
+    outs = [b.clone() for b in base]
+    bs = [torch.zeros(s[0], device=dev) for s in shapes]
+    descs = [G.gemm_desc(dy, act, D, I, Mtok, G.EPI["F32"], outs[0], rowsum=bs[0]),
+             G.gemm_desc(dh, ln2, I, D, Mtok, G.EPI["F32"], outs[1], rowsum=bs[1]),
+             G.gemm_desc(dy, ln2, D, D, Mtok, G.EPI["F32"], outs[2], rowsum=bs[2]),
+             G.gemm_desc(dqkv, ln1, 3 * D, D, Mtok, G.EPI["F32"], outs[3], rowsum=bs[3])]
+    G.run_gemm(descs, G.TN, 13)
+    torch.cuda.synchronize()
+    refs = [dy.float().t() @ act.float(), dh.float().t() @ ln2.float(), dy.float().t() @ ln2.float(), dqkv.float().t() @ ln1.float()]
+    for o, b0, r in zip(outs, base, refs):
+        assert G.rel_err(o - b0, r) < 2e-5
+    for b, x in zip(bs, (dy, dh, dy, dqkv)):
+        assert float((b - x.float().sum(0)).abs().max()) < 2e-2 * math.sqrt(Mtok / 1000.0)
+    # and the same tile config is refused for anything but plain f32 weight gradients
+    with pytest.raises(Exception):
+        G.run_gemm([G.gemm_desc(dy, G.bf16_randn(I, D, seed=3), Mtok, I, D, G.EPI["F32"], torch.zeros(Mtok, I, device=dev))], G.NT, 13)

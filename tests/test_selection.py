@@ -79,6 +79,9 @@ def test_weight_gradient_plans(L):
     assert tile == 0 and name == "bvc::gemm_kernel<128, 128, true, true, 2, 2, true>"
     tile, split, name = _plan(L, _dw_group(L, 2 * 1568, 384, 1536))          # 2 clips: far below every gate
     assert tile in (0, 1, 2) and "gemm8" not in name
+    # ViT-L layers (JEPA context encoder, 256 samples x 100 tokens): 192 tiles of 256 x 256 fill 3/4 of the chip unsplit and overflow it when
+    # split - tile config 13 (accumulated outputs) so that gemm8's balanced walk can use the idle quarter (round 4)
+    assert _plan(L, _dw_group(L, 256 * 100, 1024, 4096)) == (13, 1, "bvc::gemm8_kernel<256, 256, true, true, 2>")
     # the head's weight gradient (1536 x 384 over the masked tokens) follows the decoder rule
     assert _plan(L, [_desc(L, 1536, 384, 256 * 1408, 0, 2)])[0] == 12
 

@@ -72,6 +72,7 @@ PY
     lossdbg) run lossdbg 300 python tools/debug/g8_loss_dbg.py ;;
     dwab)  run dwab 400 python tools/dw_tile_ab.py ;;
     dwbal) run dwbal 400 python tools/dw_balance_ab.py ;;
+    dwhead) BVC_HEAD=1 run dwhead 400 python tools/dw_balance_ab.py ;;
     gemmdbg) run gemmdbg 300 python tools/gemm_dbg.py ;;
     ksweep) run ksweep 400 python tools/gemm_ksweep.py ;;
     dwsweep) run dwsweep 400 python tools/dw_sweep.py ;;

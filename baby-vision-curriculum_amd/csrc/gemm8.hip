@@ -176,6 +176,12 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const GemmGroup g, const 
         }
     }
     if (uid >= u_hi) return;       // uniform per workgroup, before any barrier
+    // experiments build (BVC_GEMM_DEBUG = 1024 + (n << 12)): every other workgroup of an XCD starts n x 3.4 us late.  All workgroups
+    // walk units of the same length from the same start, so their epilogues - the only phase with store / side-input traffic - hit
+    // the memory system together; a start offset persists for the whole launch and puts one half's epilogues under the other half's K loops.
+    if (BVC_DBG(g, 1024) && (slot_id & 1)) {
+        for (int i = 0; i < ((g.dbg >> 12) & 63); ++i) __builtin_amdgcn_s_sleep(127);
+    }
 
     // ------------------------------------------------------------------ the staging cursor (runs ahead of the compute)
     Unit su;

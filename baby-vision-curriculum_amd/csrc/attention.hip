@@ -224,6 +224,49 @@ __device__ __forceinline__ void attn_block(int tiles, int remap, int& tile, int&
     tile = lid - bh * tiles;
 }
 
+// The ragged LAST block of a sequence (round 4).  A block is four waves of 32 rows; N = 1568 leaves 32 rows for the 13th block, N = 160
+// for the second: three of its waves had no rows, ran the whole loop on clamped rows and threw the result away - the block cost as
+// much as a full one (1 / 13 of the decoder's attention time for 1 / 49 of its rows).  When at most two waves of the last block own
+// rows, the idle waves now SHARE the loop of the owners: with `valid` owning waves (1 or 2) and gs = 4 / valid waves per 32-row tile,
+// wave w works on tile w % valid and takes the 32-row sub-tiles of the other sequence dimension whose index is congruent to
+// w / valid modulo gs; the partial results of a tile (running max / sum and O for the forward, plain sums for the gradients) meet in
+// the LDS of the staging ring once the loop is over, and part 0 of each tile stores.  Barriers are untouched (every wave walks the
+// same loop); blocks with three or four owning waves run as before (gs = 1).
+struct TailSplit { int gs, own, part, valid; };
+__device__ __forceinline__ TailSplit tail_split(int N, int tile, int wave) {
+    const int rows = N - tile * 128;
+    TailSplit t;
+    t.valid = rows >= 128 ? 4 : (rows + 31) >> 5;
+    t.gs = t.valid == 1 ? 4 : t.valid == 2 ? 2 : 1;
+    t.own = t.gs == 1 ? wave : wave & (t.valid - 1);
+    t.part = t.gs == 1 ? 0 : wave >> (t.valid - 1);
+    return t;
+}
+// partial accumulators of parts 1 .. gs-1 -> part 0 through LDS (`buf`: free staging memory, NT f32x16 tiles per wave); plain sums
+template <int NT>
+__device__ __forceinline__ void tail_reduce(char* buf, const TailSplit& ts, int lane, f32x16 (&acc)[NT]) {
+    AS3 float* cl = (AS3 float*)buf;
+    constexpr int SLOT = NT * 16 * 64;
+    __syncthreads();
+    if (ts.part > 0) {
+        AS3 float* w = cl + ((ts.part - 1) * ts.valid + ts.own) * SLOT + lane;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) w[(t * 16 + r) * 64] = acc[t][r];
+    }
+    __syncthreads();
+    if (ts.part == 0) {
+        for (int p = 1; p < ts.gs; ++p) {
+            const AS3 float* w = cl + ((p - 1) * ts.valid + ts.own) * SLOT + lane;
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][r] += w[(t * 16 + r) * 64];
+        }
+    }
+}
+
 // grid ceil(N/128) * B*H (1-D, see attn_block); 256 threads; wave w owns queries q0 + 32 w .. + 31
 template <int HD>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx,
@@ -238,10 +281,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
     attn_block((N + 127) >> 7, remap, tile_, bh);
     const int b = bh / H, head = bh % H;
     const int ld = 3 * D;
-    const int qi = tile_ * 128 + wave * 32 + (lane & 31);   // this lane's query
+    const TailSplit ts = tail_split(N, tile_, wave);
+    const int qi = tile_ * 128 + ts.own * 32 + (lane & 31);   // this lane's query
     const int h = lane >> 5;
     const __amdgpu_buffer_rsrc_t rs = make_rsrc(qkv, qkv_bytes);
     const FragAddr<HD> fa = make_frag_addr<HD>(lane);
+    const int gm = ts.gs - 1;
+    auto mine = [&](int sub) { return (sub & gm) == ts.part; };      // does this wave take 32-key sub-tile `sub`?
 
     bf16x8 qf[HD / 16];   // Q^T fragments (B operand of S^T = K Q^T): Q[qi][16 step + 8 h + 0..7]
     {
@@ -267,18 +313,48 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (kt + 1 < nkt) issue(kt + 1, 1);
-        fwd_subtile<HD, 0, IMG>(lds, fa, qf, st, kt * 64, N, h, scale_log2);
-        if (kt * 64 + 32 < N) fwd_subtile<HD, SUB, IMG + SUB>(lds, fa, qf, st, kt * 64 + 32, N, h, scale_log2);
+        if (mine(2 * kt)) fwd_subtile<HD, 0, IMG>(lds, fa, qf, st, kt * 64, N, h, scale_log2);
+        if (kt * 64 + 32 < N && mine(2 * kt + 1)) fwd_subtile<HD, SUB, IMG + SUB>(lds, fa, qf, st, kt * 64 + 32, N, h, scale_log2);
         if (kt + 1 >= nkt) break;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (kt + 2 < nkt) issue(kt + 2, 0);
-        fwd_subtile<HD, STG, STG + IMG>(lds, fa, qf, st, kt * 64 + 64, N, h, scale_log2);
-        if (kt * 64 + 96 < N) fwd_subtile<HD, STG + SUB, STG + IMG + SUB>(lds, fa, qf, st, kt * 64 + 96, N, h, scale_log2);
+        if (mine(2 * kt + 2)) fwd_subtile<HD, STG, STG + IMG>(lds, fa, qf, st, kt * 64 + 64, N, h, scale_log2);
+        if (kt * 64 + 96 < N && mine(2 * kt + 3)) fwd_subtile<HD, STG + SUB, STG + IMG + SUB>(lds, fa, qf, st, kt * 64 + 96, N, h, scale_log2);
+    }
+    if (ts.gs > 1) {      // workgroup-uniform: merge the parts of a query tile (flash-decoding style: common maximum, rescaled sums)
+        AS3 float* cl = (AS3 float*)smem;
+        constexpr int NO = HD / 32 * 16, SLOT = (NO + 2) * 64;
+        __syncthreads();
+        if (ts.part > 0) {
+            AS3 float* w = cl + ((ts.part - 1) * ts.valid + ts.own) * SLOT + lane;
+#pragma unroll
+            for (int t = 0; t < HD / 32; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) w[(t * 16 + r) * 64] = st.o[t][r];
+            w[NO * 64] = st.m_run;
+            w[(NO + 1) * 64] = st.l_run;
+        }
+        __syncthreads();
+        if (ts.part == 0) {
+            for (int p = 1; p < ts.gs; ++p) {
+                const AS3 float* w = cl + ((p - 1) * ts.valid + ts.own) * SLOT + lane;
+                const float m_p = w[NO * 64], l_p = w[(NO + 1) * 64];
+                const float m_new = fmaxf(st.m_run, m_p);
+                const float a = st.m_run == -INFINITY ? 0.f : fast_exp2(st.m_run - m_new);     // (a part that saw no key: -inf, weight 0)
+                const float c = m_p == -INFINITY ? 0.f : fast_exp2(m_p - m_new);
+                st.m_run = m_new;
+                st.l_run = st.l_run * a + l_p * c;
+#pragma unroll
+                for (int t = 0; t < HD / 32; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) st.o[t][r] = st.o[t][r] * a + w[(t * 16 + r) * 64] * c;
+            }
+        }
     }
     const float l_tot = xhalf_sum(st.l_run);
     const float inv = 1.f / l_tot;
-    if (qi < N) {
+    if (qi < N && ts.part == 0) {
         bf16_t* orow = ctx + (size_t)(b * N + qi) * D + head * HD;
 #pragma unroll
         for (int t = 0; t < HD / 32; ++t)
@@ -336,11 +412,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
     attn_block((N + 127) >> 7, remap, tile_, bh);
     const int b = bh / H, head = bh % H;
     const int ld = 3 * D;
-    const int qi = tile_ * 128 + wave * 32 + (lane & 31);
+    const TailSplit ts = tail_split(N, tile_, wave);      // the ragged last block: idle waves share the key loop of the owners
+    const int qi = tile_ * 128 + ts.own * 32 + (lane & 31);
     const int qc = min(qi, N - 1);
     const int h = lane >> 5;
     const __amdgpu_buffer_rsrc_t rs = make_rsrc(qkv, qkv_bytes);
     const FragAddr<HD> fa = make_frag_addr<HD>(lane);
+    const int gm = ts.gs - 1;
+    auto mine = [&](int sub) { return (sub & gm) == ts.part; };
 
     bf16x8 qf[HD / 16], dof[HD / 16];
     float del_q = 0.f;
@@ -360,7 +439,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
         }
     }
     del_q += __shfl_xor(del_q, 32, 64);
-    if (h == 0 && qi < N) delta[(size_t)bh * N + qi] = -del_q;     // NEGATED: the dK/dV kernel, launched after this one, starts its dP chain from it
+    if (h == 0 && qi < N && ts.part == 0) delta[(size_t)bh * N + qi] = -del_q;     // NEGATED: the dK/dV kernel, launched after this one, starts its dP chain from it
     float nlse = -lse[(size_t)bh * N + qc];
 #pragma unroll
     for (int stq = 0; stq < HD / 16; ++stq) { settle(qf[stq]); settle(dof[stq]); }
@@ -383,17 +462,18 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const bf16_t* __res
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (kt + 1 < nkt) issue(kt + 1, 1);
-        dq_subtile<HD, 0, IMG>(lds, fa, qf, dof, dq, kt * 64, N, h, scale_log2, nlse, ndel);
-        if (kt * 64 + 32 < N) dq_subtile<HD, SUB, IMG + SUB>(lds, fa, qf, dof, dq, kt * 64 + 32, N, h, scale_log2, nlse, ndel);
+        if (mine(2 * kt)) dq_subtile<HD, 0, IMG>(lds, fa, qf, dof, dq, kt * 64, N, h, scale_log2, nlse, ndel);
+        if (kt * 64 + 32 < N && mine(2 * kt + 1)) dq_subtile<HD, SUB, IMG + SUB>(lds, fa, qf, dof, dq, kt * 64 + 32, N, h, scale_log2, nlse, ndel);
         if (kt + 1 >= nkt) break;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (kt + 2 < nkt) issue(kt + 2, 0);
-        dq_subtile<HD, STG, STG + IMG>(lds, fa, qf, dof, dq, kt * 64 + 64, N, h, scale_log2, nlse, ndel);
-        if (kt * 64 + 96 < N)
+        if (mine(2 * kt + 2)) dq_subtile<HD, STG, STG + IMG>(lds, fa, qf, dof, dq, kt * 64 + 64, N, h, scale_log2, nlse, ndel);
+        if (kt * 64 + 96 < N && mine(2 * kt + 3))
             dq_subtile<HD, STG + SUB, STG + IMG + SUB>(lds, fa, qf, dof, dq, kt * 64 + 96, N, h, scale_log2, nlse, ndel);
     }
-    if (qi < N) {
+    if (ts.gs > 1) tail_reduce<HD / 32>(smem, ts, lane, dq);
+    if (qi < N && ts.part == 0) {
         bf16_t* orow = dqkv + (size_t)(b * N + qi) * ld + head * HD;
 #pragma unroll
         for (int t = 0; t < HD / 32; ++t)
@@ -482,9 +562,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const bf16_t* __r
     attn_block((N + 127) >> 7, remap, tile_, bh);
     const int b = bh / H, head = bh % H;
     const int ld = 3 * D;
-    const int ki = tile_ * 128 + wave * 32 + (lane & 31);   // this lane's key
+    const TailSplit ts = tail_split(N, tile_, wave);      // the ragged last key block: idle waves share the query loop of the owners
+    const int ki = tile_ * 128 + ts.own * 32 + (lane & 31);   // this lane's key
     const int kc = min(ki, N - 1);
     const int h = lane >> 5;
+    const int gm = ts.gs - 1;
+    auto mine = [&](int sub) { return (sub & gm) == ts.part; };
     const __amdgpu_buffer_rsrc_t rq = make_rsrc(qkv, qkv_bytes);
     const __amdgpu_buffer_rsrc_t rd = make_rsrc(dctx, dctx_bytes);
     const __amdgpu_buffer_rsrc_t rl = make_rsrc(lse, stat_bytes);
@@ -519,16 +602,20 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const bf16_t* __r
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (qt + 1 < nqt) issue(qt + 1, 1);
-        dkdv_subtile<HD, 0, 2 * IMG>(lds, fa, kf, vf, dk, dv, qt * 64, N, h, scale_log2);
-        if (qt * 64 + 32 < N) dkdv_subtile<HD, SUB, 2 * IMG + 128>(lds, fa, kf, vf, dk, dv, qt * 64 + 32, N, h, scale_log2);
+        if (mine(2 * qt)) dkdv_subtile<HD, 0, 2 * IMG>(lds, fa, kf, vf, dk, dv, qt * 64, N, h, scale_log2);
+        if (qt * 64 + 32 < N && mine(2 * qt + 1)) dkdv_subtile<HD, SUB, 2 * IMG + 128>(lds, fa, kf, vf, dk, dv, qt * 64 + 32, N, h, scale_log2);
         if (qt + 1 >= nqt) break;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (qt + 2 < nqt) issue(qt + 2, 0);
-        dkdv_subtile<HD, STG, STG + 2 * IMG>(lds, fa, kf, vf, dk, dv, qt * 64 + 64, N, h, scale_log2);
-        if (qt * 64 + 96 < N) dkdv_subtile<HD, STG + SUB, STG + 2 * IMG + 128>(lds, fa, kf, vf, dk, dv, qt * 64 + 96, N, h, scale_log2);
+        if (mine(2 * qt + 2)) dkdv_subtile<HD, STG, STG + 2 * IMG>(lds, fa, kf, vf, dk, dv, qt * 64 + 64, N, h, scale_log2);
+        if (qt * 64 + 96 < N && mine(2 * qt + 3)) dkdv_subtile<HD, STG + SUB, STG + 2 * IMG + 128>(lds, fa, kf, vf, dk, dv, qt * 64 + 96, N, h, scale_log2);
     }
-    if (ki < N) {
+    if (ts.gs > 1) {      // (one accumulator set at a time: three partial sets of 8 KiB fit the 33 KiB ring, six do not)
+        tail_reduce<HD / 32>(smem, ts, lane, dk);
+        tail_reduce<HD / 32>(smem, ts, lane, dv);
+    }
+    if (ki < N && ts.part == 0) {
         bf16_t* krow = dqkv + (size_t)(b * N + ki) * ld + D + head * HD;
         bf16_t* vrow = krow + D;
 #pragma unroll

@@ -216,7 +216,7 @@ def _ref_attention(qkv, B, N, H, HD=64):
 
 
 @pytest.mark.parametrize("HD", [64, 32])
-@pytest.mark.parametrize("B,N,H", [(2, 160, 2), (1, 1568, 2), (3, 100, 1), (2, 24, 1), (1, 392, 3), (4, 108, 12), (2, 161, 1), (1, 320, 2)])
+@pytest.mark.parametrize("B,N,H", [(2, 160, 2), (1, 1568, 2), (3, 100, 1), (2, 24, 1), (1, 392, 3), (4, 108, 12), (2, 161, 1), (1, 320, 2), (1, 192, 2), (2, 129, 1)])
 def test_attention_forward(B, N, H, HD):
     D = HD * H
     qkv = G.bf16_randn(B * N, 3 * D, seed=30)
@@ -231,7 +231,7 @@ def test_attention_forward(B, N, H, HD):
 
 
 @pytest.mark.parametrize("HD", [64, 32])
-@pytest.mark.parametrize("B,N,H", [(2, 160, 2), (1, 1568, 1), (3, 100, 1), (2, 24, 1), (4, 108, 12), (2, 161, 1), (1, 320, 2)])
+@pytest.mark.parametrize("B,N,H", [(2, 160, 2), (1, 1568, 1), (3, 100, 1), (2, 24, 1), (4, 108, 12), (2, 161, 1), (1, 320, 2), (1, 192, 2), (2, 129, 1)])
 def test_attention_backward(B, N, H, HD):
     D = HD * H
     qkv = G.bf16_randn(B * N, 3 * D, seed=31)

@@ -57,14 +57,15 @@ __device__ __forceinline__ int swz_dual(int r) {
 
 // stage rows [row0, row0+64) x HD bf16 starting at element column `col0` of a [rows][ld] bf16 array
 // into a 64 x HD LDS image (8 KiB / 4 KiB); pieces of 1 KiB, two / one per wave
-template <int HD>
+template <int HD, int NW = 4>
 __device__ __forceinline__ void stage64(__amdgpu_buffer_rsrc_t rs, int row0, int ld, int col0, char* lds,
                                         int wave, int lane) {
     constexpr int CPR = HD / 8;                 // 16-B chunks per row
     constexpr int RPP = 64 / CPR;               // rows per 1 KiB piece
 #pragma unroll
-    for (int jj = 0; jj < HD / 32; ++jj) {
-        const int j = wave + 4 * jj;
+    for (int jj = 0; jj < (HD / 8 + NW - 1) / NW; ++jj) {
+        const int j = wave + NW * jj;
+        if (NW > HD / 8 && j >= HD / 8) break;      // (more waves than pieces: wave-uniform)
         const int r = RPP * j + lane / CPR;
         const int c = (lane % CPR) ^ swz_dual<HD>(r);
         const uint32_t off = (uint32_t)(((size_t)(row0 + r) * ld + col0 + c * 8) * 2);
@@ -233,7 +234,9 @@ __device__ __forceinline__ void attn_block(int tiles, int remap, int& tile, int&
 // the LDS of the staging ring once the loop is over, and part 0 of each tile stores.  Barriers are untouched (every wave walks the
 // same loop); blocks with three or four owning waves run as before (gs = 1).
 struct TailSplit { int gs, own, part, valid; };
+template <int NW = 4>
 __device__ __forceinline__ TailSplit tail_split(int N, int tile, int wave) {
+    if constexpr (NW != 4) { TailSplit t; t.valid = NW; t.gs = 1; t.own = wave; t.part = 0; return t; }     // (experiment: 8-wave blocks, no split)
     const int rows = N - tile * 128;
     TailSplit t;
     t.valid = rows >= 128 ? 4 : (rows + 31) >> 5;
@@ -268,8 +271,8 @@ __device__ __forceinline__ void tail_reduce(char* buf, const TailSplit& ts, int 
 }
 
 // grid ceil(N/128) * B*H (1-D, see attn_block); 256 threads; wave w owns queries q0 + 32 w .. + 31
-template <int HD>
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx,
+template <int HD, int NW = 4>
+__global__ __launch_bounds__(64 * NW, 2) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ ctx,
                                                           float* __restrict__ lse, int N, int H, int D,
                                                           uint32_t qkv_bytes, float scale_log2, int remap) {
     extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 stages x (K image + V image)
@@ -278,11 +281,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int tile_, bh;
-    attn_block((N + 127) >> 7, remap, tile_, bh);
+    attn_block((N + 32 * NW - 1) / (32 * NW), remap, tile_, bh);
     const int b = bh / H, head = bh % H;
     const int ld = 3 * D;
-    const TailSplit ts = tail_split(N, tile_, wave);
-    const int qi = tile_ * 128 + ts.own * 32 + (lane & 31);   // this lane's query
+    const TailSplit ts = tail_split<NW>(N, tile_, wave);
+    const int qi = tile_ * (32 * NW) + ts.own * 32 + (lane & 31);   // this lane's query
     const int h = lane >> 5;
     const __amdgpu_buffer_rsrc_t rs = make_rsrc(qkv, qkv_bytes);
     const FragAddr<HD> fa = make_frag_addr<HD>(lane);
@@ -303,8 +306,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const bf16_t* __restri
     const int nkt = (N + 63) >> 6;
     const int krow0 = b * N;
     auto issue = [&](int kt, int stage) {
-        stage64<HD>(rs, krow0 + kt * 64, ld, D + head * HD, smem + stage * STG, wave, lane);
-        stage64<HD>(rs, krow0 + kt * 64, ld, 2 * D + head * HD, smem + stage * STG + IMG, wave, lane);
+        stage64<HD, NW>(rs, krow0 + kt * 64, ld, D + head * HD, smem + stage * STG, wave, lane);
+        stage64<HD, NW>(rs, krow0 + kt * 64, ld, 2 * D + head * HD, smem + stage * STG + IMG, wave, lane);
     };
 #pragma unroll
     for (int stq = 0; stq < HD / 16; ++stq) settle(qf[stq]);
@@ -882,8 +885,17 @@ static int fwd_hd(const bf16_t* qkv, bf16_t* ctx, float* lse, int B, int N, int 
     const int D = H * HD;
     const size_t bytes = (size_t)B * N * 3 * D * 2;
     const float scale_log2 = (sm_scale > 0.f ? sm_scale : 1.0f / sqrtf((float)HD)) * 1.4426950408889634f;
+#ifdef BVC_EXPERIMENTS
+    if (getenv("BVC_ATTN_NW8") != nullptr) {      // 256-query blocks (eight waves): half the K / V staging per query - same-process A/B only
+        const dim3 grid8((unsigned)(((N + 255) / 256) * B * H));
+        hipLaunchKernelGGL((attn_fwd_kernel<HD, 8>), grid8, dim3(512), 4 * 64 * HD * 2, stream, qkv, ctx, lse, N, H, D, (uint32_t)bytes, scale_log2,
+                           xcd_remap());
+        BVC_CHECK_HIP(hipGetLastError());
+        return BVC_OK;
+    }
+#endif
     const dim3 grid((unsigned)(((N + 127) / 128) * B * H));
-    hipLaunchKernelGGL(attn_fwd_kernel<HD>, grid, dim3(256), 4 * 64 * HD * 2, stream, qkv, ctx, lse, N, H, D, (uint32_t)bytes, scale_log2,
+    hipLaunchKernelGGL((attn_fwd_kernel<HD, 4>), grid, dim3(256), 4 * 64 * HD * 2, stream, qkv, ctx, lse, N, H, D, (uint32_t)bytes, scale_log2,
                        xcd_remap());
     BVC_CHECK_HIP(hipGetLastError());
     return BVC_OK;

@@ -74,6 +74,7 @@ PY
     dwbal) run dwbal 400 python tools/dw_balance_ab.py ;;
     dwhead) BVC_HEAD=1 run dwhead 400 python tools/dw_balance_ab.py ;;
     phase) run phase 500 python tools/phase_ab.py ;;
+    attnnw) run attnnw 400 python tools/attn_nw_ab.py ;;
     gemmdbg) run gemmdbg 300 python tools/gemm_dbg.py ;;
     ksweep) run ksweep 400 python tools/gemm_ksweep.py ;;
     dwsweep) run dwsweep 400 python tools/dw_sweep.py ;;

@@ -93,7 +93,9 @@ for layout, epi, M, N, K, tile in cases:
 
 # the split-K weight-gradient group of one layer (class 2 with atomics), encoder and decoder widths, as plan_dw launches it
 for tag, M, D, I, tile, split in (("enc", 20480, 768, 3072, 10, 2), ("dec", 100352, 384, 1536, 10, 6), ("dec", 50176, 384, 1536, 11, 4),
-                                 ("dec", 100352, 384, 1536, 12, 7), ("dec", 25088, 384, 1536, 12, 7)):
+                                 ("dec", 100352, 384, 1536, 12, 7), ("dec", 25088, 384, 1536, 12, 7),
+                                 # round 4: the balanced walk (enc: 216 units + 108 tails) at 64 clips; tile config 13 (accumulated, unsplit, ViT-L widths)
+                                 ("enc", 10240, 768, 3072, 10, 2), ("vit-l", 25600, 1024, 4096, 13, 1)):
     dy, act = G.bf16_randn(M, D, seed=7), G.bf16_randn(M, I, seed=8)
     dh, ln2 = G.bf16_randn(M, I, seed=9), G.bf16_randn(M, D, seed=10)
     dqkv = G.bf16_randn(M, 3 * D, seed=11)

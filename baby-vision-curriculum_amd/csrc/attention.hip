@@ -503,8 +503,46 @@ __device__ __forceinline__ void dkdv_subtile(const AS3 char* lds, const FragAddr
                                              int N, int h, float scale_log2) {
     constexpr int IMG = 64 * HD * 2, KS = 16 * HD * 2;
     constexpr int DOFF = QOFF + IMG;
-    // rows of s/dp are queries: registers 4g..4g+3 <-> queries q0 + 8 g + 4 h + 0..3 (lse / -delta broadcast from LDS).
-    // The dP chain starts from -delta (the dQ kernel stores it negated): four 16-byte LDS reads ARE the initial accumulator.
+#ifndef BVC_ATTN_STATS_LDS
+    // Rows of s / dp are queries, so the row statistics (lse, -delta) are the same for every lane: broadcast reads.  Until round 4 they
+    // came as eight 16-byte LDS reads per sub-tile - a third of the LDS bytes of a kernel that is bound by LDS bandwidth.  Now they
+    // enter through the MFMA pipe, which has the slack: one more k-step per chain whose A operand (query on the row) carries
+    // [-lse / c (hi, lo), -delta (hi, lo), 0 ...] as bf16 hi + lo pairs (16 mantissa bits: 2^-17 relative, 5e-5 on P) and whose B operand is
+    // a per-lane CONSTANT (ones in the two k rows of the chain's statistic).  Two 4-byte LDS reads, ~12 vector instructions and two MFMAs
+    // replace eight 16-byte reads and sixteen multiply-adds: S' = Q K^T - lse / c, then P = exp2(c S'); dP' = dO V^T - delta.
+    bf16x8 sfrag, one_s, one_d;
+    {
+        const AS3 float* st = reinterpret_cast<const AS3 float*>(lds + STAT);
+        const int r = threadIdx.x & 31;
+        const float xl = -st[r] * (1.0f / scale_log2), xd = st[64 + r];        // (the dQ kernel stores delta negated)
+        const uint32_t hh = pack2bf(xl, xd);                                     // the two high parts: lse' in bits 0-15, delta' in 16-31
+        const float lhi = __uint_as_float(hh << 16), dhi = __uint_as_float(hh & 0xffff0000u);
+        const uint32_t ll = pack2bf(xl - lhi, xd - dhi);                         // the two low parts
+        union { bf16x8 v; uint32_t u[4]; } f, a, b;
+        f.u[0] = h ? 0u : ((hh & 0xffffu) | (ll << 16));                         // k rows 0, 1: lse' hi, lo
+        f.u[1] = h ? 0u : ((hh >> 16) | (ll & 0xffff0000u));                     // k rows 2, 3: delta' hi, lo
+        f.u[2] = 0u; f.u[3] = 0u;
+        a.u[0] = h ? 0u : 0x3f803f80u; a.u[1] = 0u; a.u[2] = 0u; a.u[3] = 0u;      // bf16 1.0 twice: k rows 0, 1
+        b.u[0] = 0u; b.u[1] = h ? 0u : 0x3f803f80u; b.u[2] = 0u; b.u[3] = 0u;      // k rows 2, 3
+        sfrag = f.v; one_s = a.v; one_d = b.v;
+    }
+    f32x16 s = zero16(), dp = zero16();
+#pragma unroll
+    for (int stp = 0; stp < HD / 16; ++stp) {
+        s = MFMA32(lds_rows<QOFF>(lds, fa.rows[stp]), kf[stp], s);
+        dp = MFMA32(lds_rows<DOFF>(lds, fa.rows[stp]), vf[stp], dp);
+    }
+    s = MFMA32(sfrag, one_s, s);
+    dp = MFMA32(sfrag, one_d, dp);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float p = fast_exp2(s[r] * scale_log2);
+        s[r] = p;
+        dp[r] = p * dp[r];
+    }
+#else
+    // (the round-2 form, kept for the A/B: rows of s/dp are queries: registers 4g..4g+3 <-> queries q0 + 8 g + 4 h + 0..3, lse / -delta
+    //  broadcast from LDS; the dP chain starts from -delta: four 16-byte LDS reads ARE the initial accumulator)
     const AS3 float* stl = reinterpret_cast<const AS3 float*>(lds + STAT) + 4 * h;
     f32x16 s = zero16(), dp;
 #pragma unroll
@@ -529,6 +567,7 @@ __device__ __forceinline__ void dkdv_subtile(const AS3 char* lds, const FragAddr
             dp[r] = p * dp[r];
         }
     }
+#endif
     if (q0 + 32 > N) {
         asm volatile("" ::: "memory");
 #pragma unroll

@@ -295,8 +295,23 @@ def main():
             by_batch[str(b)] = {"value": round(b * 10 / wall, 2), "unit": "clips/s", "ms_per_step": round(1e3 * wall / 10, 4), "steps": 10,
                                 "roofline": {"bound": "mfma", "achieved": round(tf, 2), "frac": round(tf / PEAK_BF16_TFLOPS, 4), "traffic": tr}}
         clips, B = full, args.batch
+    comm = None
+    if use_ddp:
+        # two more steps OUTSIDE the timed region with per-bucket events on the communication stream: bytes, time, ring bus bandwidth
+        xmodel.profile_buckets = True
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        rep = xmodel.bucket_report()
+        native = bvc.comm.get(dev)
+        comm = {"backend": ("rccl via libbvc_hip.so (bvc_allreduce_bucket / bvc_allreduce; BVC_COMM=bvc): " + native.library)
+                if xmodel.comm_backend == "bvc-rccl" else "rccl via torch.distributed (nccl), the script's process group (default)",
+                "communicators_in_step": 1,
+                "ranks": dist.get_world_size(), "bucket_cap_mb": args.bucket_mb, "buckets_last_step": rep[-1] if rep else []}
+        xmodel.profile_buckets = False
     # BASELINE configs 4 / 5 on this GPU, outside every timed region of the headline metric (tools/bench_legs.py): their own
     # metrics, units and FLOP counts; never part of `value`
+    # (after the data-parallel report above: this block frees the headline model)
     extra = None
     if world == 1 and not args.stream_input and not args.no_extra:
         from tools import bench_legs
@@ -312,20 +327,6 @@ def main():
             except Exception as e:      # noqa: BLE001 - the headline line must not depend on an extra leg
                 extra[key] = {"error": f"{type(e).__name__}: {e}"}
             torch.cuda.empty_cache()
-    comm = None
-    if use_ddp:
-        # two more steps OUTSIDE the timed region with per-bucket events on the communication stream: bytes, time, ring bus bandwidth
-        xmodel.profile_buckets = True
-        for _ in range(2):
-            step()
-        torch.cuda.synchronize()
-        rep = xmodel.bucket_report()
-        native = bvc.comm.get(dev)
-        comm = {"backend": ("rccl via libbvc_hip.so (bvc_allreduce_bucket / bvc_allreduce; BVC_COMM=bvc): " + native.library)
-                if xmodel.comm_backend == "bvc-rccl" else "rccl via torch.distributed (nccl), the script's process group (default)",
-                "communicators_in_step": 1,
-                "ranks": dist.get_world_size(), "bucket_cap_mb": args.bucket_mb, "buckets_last_step": rep[-1] if rep else []}
-        xmodel.profile_buckets = False
     stream_info = None
     if ring is not None:
         stream_info = {"bytes_per_step": B * 16 * 3 * 224 * 224, "ring_depth": ring.depth,

@@ -272,3 +272,26 @@ def test_torch_distributed_is_the_default(monkeypatch, value):
     finally:
         bvc.comm.reset()
         dist.destroy_process_group()
+
+
+def test_bench_line_under_the_forced_wrapper_one_rank():
+    """`bench.py` exactly as the driver starts a rank (torch.distributed.run, one process), with the data-parallel wrapper forced on a
+    world of one: the line must carry the communication report AND the extra legs (round 4: the extra block freed the headline model
+    before the report's two profiled steps ran - a crash only this combination reached)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BVC_FORCE_DDP="1", MASTER_ADDR="127.0.0.1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "8",
+           "--no-cpu-baseline", "--no-by-batch"]
+    p = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 1 and d["comm"]["buckets_last_step"], d.get("comm")
+    assert set(d["extra"]) == {"jepa_vit_large_b16", "jepa_vit_large_b256", "simclr_vit_base_512"}
+    assert not any("error" in v for v in d["extra"].values()), d["extra"]

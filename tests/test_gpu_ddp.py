@@ -286,7 +286,7 @@ def test_bench_line_under_the_forced_wrapper_one_rank():
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
         env.pop(k, None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
-           "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "8",
+           "--master-port", "29541", os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "8",
            "--no-cpu-baseline", "--no-by-batch"]
     p = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-3000:]

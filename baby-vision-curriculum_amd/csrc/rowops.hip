@@ -463,6 +463,85 @@ __global__ __launch_bounds__(256, 6) void labels_wave_kernel(const PixelSrc clip
     }
 }
 
+// Three channels, E a multiple of 256 (the reference's 2 x 16 x 16 tubes: E = 512) - the same wave-per-token form with the arithmetic
+// cut down (round 4): the strip experiment (profiles/r04_y_labels_strip_kernel.patch.txt) showed that a token cost a wave ~20 us of
+// vector work, not of memory time.  Here (a) the statistics come from the lane's own registers (a lane's chunks k = 2c, 2c + 1 are channel
+// c: eight values per channel, two-pass mean / unbiased variance with one wave_sum each) instead of 48 LDS reads; (b) C is a constant, so
+// the (element, channel) of an output position costs a multiply-shift instead of a runtime division (24 of them per lane before);
+// (c) one IEEE division per channel (1 / (sqrt(var) + 1e-6)) and a multiply per value instead of a division per value: within one f32
+// rounding of (f - mean) / (sqrt(var) + 1e-6).  The per-lane channel of output position 4 lane + 256 k + j is (lane + k + j) mod 3, so
+// with the channel statistics rotated by lane mod 3 once, every use is a compile-time register.
+template <int NE>      // NE = E / 256: chunks per lane and channel
+__global__ __launch_bounds__(256, 6) void labels_wave3_kernel(const PixelSrc clip, const int* __restrict__ msk_idx, float* __restrict__ labels,
+                                                              int ntok, int nmask, PatchGeom pg, int norm_pix) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int C = 3, E = 256 * NE, CE = C * E, NCH = C * NE;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* buf = reinterpret_cast<float*>(smem) + wave * CE;                          // [C][E], this wave's token
+    const int nb = gridDim.x, xq = nb >> 3, xr = nb & 7, xcd = blockIdx.x & 7;
+    const int blk = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (blockIdx.x >> 3);
+    const int m = blk * 4 + wave;
+    if (m >= ntok) return;
+    const int b = m / nmask, tok = msk_idx[m];
+    const int wp = pg.W / pg.ps, hp = pg.H / pg.ps;
+    const int tp = tok / (hp * wp), yp = (tok / wp) % hp, xp = tok % wp;
+    const float mean3[3] = {0.485f, 0.456f, 0.406f}, std3[3] = {0.229f, 0.224f, 0.225f};
+    f32x4 v[NCH];
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        constexpr int e4n = E / 4;
+        const int i = lane + 64 * k;
+        const int c = k / NE, e = (i - c * e4n) * 4;                 // (64 NE chunks per channel: chunk k of a lane is channel k / NE)
+        const int dx = e % pg.ps, dy = (e / pg.ps) % pg.ps, dt = e / (pg.ps * pg.ps);
+        const size_t src = ((((size_t)b * pg.T + tp * pg.ts + dt) * C + c) * pg.H + yp * pg.ps + dy) * pg.W + xp * pg.ps + dx;
+        v[k] = load_pixels4(clip, src, c);
+    }
+    float mu[3], rinv[3];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        float sm = 0.f;
+#pragma unroll
+        for (int k = c * NE; k < (c + 1) * NE; ++k) {
+            v[k] = v[k] * std3[c] + mean3[c];
+            *reinterpret_cast<f32x4*>(buf + c * E + (lane + 64 * (k - c * NE)) * 4) = v[k];
+            sm += (v[k][0] + v[k][1]) + (v[k][2] + v[k][3]);
+        }
+        const float mean = wave_sum(sm) * (1.0f / E);
+        float q = 0.f;
+#pragma unroll
+        for (int k = c * NE; k < (c + 1) * NE; ++k)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const float d = v[k][j] - mean; q += d * d; }
+        const float var = wave_sum(q) / (float)(E - 1);
+        mu[c] = norm_pix ? mean : 0.f;
+        rinv[c] = norm_pix ? 1.0f / (sqrtf(var) + 1e-6f) : 1.f;
+    }
+    // statistics rotated by lane mod 3: mr[i] = mu[(lane + i) mod 3]
+    const int l3 = lane % 3;
+    float mr[3], rr[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int c = l3 + i;      // 0 .. 4
+        mr[i] = (c == 0 || c == 3) ? mu[0] : (c == 1 || c == 4) ? mu[1] : mu[2];
+        rr[i] = (c == 0 || c == 3) ? rinv[0] : (c == 1 || c == 4) ? rinv[1] : rinv[2];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    float* out = labels + (size_t)m * CE;
+#pragma unroll
+    for (int k = 0; k < CE / 256; ++k) {
+        const int o = lane * 4 + 256 * k;
+        f32x4 r;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int t = o + j, e = t / 3, c = t - 3 * e;           // output position t = e * C + c
+            r[j] = (buf[c * E + e] - mr[(k + j) % 3]) * rr[(k + j) % 3];
+        }
+        *reinterpret_cast<f32x4*>(out + o) = r;
+    }
+}
+
 // x_full[b][nvis + j][:] = mask_token + pos[msk_idx[b][j]]   (HF:580-582)
 __global__ void fill_masked_kernel(float* __restrict__ xfull, const float* __restrict__ mask_token, const float* __restrict__ pos,
                                    const int* __restrict__ msk_idx, int B, int L, int nvis, int nmask, int D) {
@@ -970,6 +1049,13 @@ int launch_labels(PixelSrc clip, const int* msk_idx, float* labels, int B, int n
     const size_t lds = (size_t)(pg.C * E + 2 * pg.C) * 4;
     // one wave per token when a token is at most 8 x 64 chunks of 16 bytes (C E <= 2048 values: every configuration of the reference)
     const int nchunk = pg.C * (E >> 2), ntok = B * nmask;
+    if (pg.C == 3 && (E == 512 || E == 256)) {      // the reference's tubes: constant channel count, statistics from registers
+        const int nblk = (ntok + 3) / 4;
+        if (E == 512) hipLaunchKernelGGL(labels_wave3_kernel<2>, dim3(nblk), dim3(256), (size_t)4 * 3 * E * 4, s, clip, msk_idx, labels, ntok, nmask, pg, norm_pix);
+        else hipLaunchKernelGGL(labels_wave3_kernel<1>, dim3(nblk), dim3(256), (size_t)4 * 3 * E * 4, s, clip, msk_idx, labels, ntok, nmask, pg, norm_pix);
+        BVC_CHECK_HIP(hipGetLastError());
+        return BVC_OK;
+    }
     if (nchunk <= 512 && lds <= 16384) {
         const int per_wave = (pg.C * E + 2 * pg.C + 3) & ~3;
         const int nblk = (ntok + 3) / 4;

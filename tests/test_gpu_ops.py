@@ -367,7 +367,7 @@ def test_colsum(M, N):
 
 
 # --------------------------------------------------------------------------- index / pixel kernels
-@pytest.mark.parametrize("cfg,B,ratio", [(vo.BASE, 3, 0.9), (vo.TINY, 4, 0.75)])
+@pytest.mark.parametrize("cfg,B,ratio", [(vo.BASE, 3, 0.9), (vo.TINY, 4, 0.75), (vo.BASE, 2, 0.4), (vo.BASE, 2, 0.6)])
 def test_mask_index_gather_labels(cfg, B, ratio):
     pixels, mask = vo.synthetic_batch(cfg, B, seed=3, mask_ratio=ratio)
     Lq = cfg.seq_len

@@ -56,6 +56,19 @@ def pixel_format(pixel_values, mean, std, channels):
     return f
 
 
+OPT_MAX_GROUPS = 8     # BVC_OPT_MAX_GROUPS (include/bvc.h)
+
+
+class SgdGroupsC(ctypes.Structure):
+    _fields_ = [("ngroups", c_int)] + [(n, c_float * OPT_MAX_GROUPS) for n in ("lr", "momentum", "dampening", "weight_decay")] + \
+               [(n, c_int * OPT_MAX_GROUPS) for n in ("nesterov", "first_step", "maximize")]
+
+
+class AdamGroupsC(ctypes.Structure):
+    _fields_ = [("ngroups", c_int)] + [(n, ctypes.c_double * OPT_MAX_GROUPS) for n in ("lr", "beta1", "beta2", "eps", "weight_decay")] + \
+               [(n, c_int * OPT_MAX_GROUPS) for n in ("decoupled", "maximize")]
+
+
 class GemmDesc(ctypes.Structure):
     _fields_ = [
         ("A", c_void_p), ("B", c_void_p),
@@ -147,6 +160,10 @@ SYMBOLS = {
     "bvc_op_adam_prepare": (c_int, [c_void_p, c_double, c_double, c_double, c_void_p, c_void_p]),
     "bvc_op_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_double, c_double, c_double, c_double, c_double,
                                  c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "bvc_op_sgd_step_segments": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                                         c_int, c_void_p, c_void_p]),
+    "bvc_op_adam_step_segments": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                                          c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "bvc_op_nonfinite_check": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     "bvc_op_mask_index": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "bvc_op_gather_patches": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),

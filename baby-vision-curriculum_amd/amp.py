@@ -20,21 +20,27 @@ class GradScaler(torch.amp.GradScaler):
         try:
             _scale, _ = self._check_scale_growth_tracker("_check_inf_per_device")
             states = self._per_optimizer_states
-            runs = []
-            for group in optimizer.param_groups:
-                runs += SGD._contiguous_runs(group["params"])
+            ranges = []       # (gradient address, elements, device)
+            if hasattr(optimizer, "_get_plans"):
+                # bvc.optim: a flat module's whole gradient buffer is ONE range whatever the parameter groups (gradients of frozen
+                # parameters are the buffer's zeros); parameters outside flat buffers go by adjacent runs
+                plans, loose = optimizer._get_plans()
+                ranges += [(pl.gbase, pl.n, pl.module._flat.device) for pl in plans]
+                for gi, ps in loose.items():
+                    ranges += [(run[0].grad.data_ptr(), sum(p.numel() for p in run), run[0].device) for run in optimizer._group_runs(gi, ps)]
+            else:
+                for group in optimizer.param_groups:
+                    ranges += [(run[0].grad.data_ptr(), sum(p.numel() for p in run), run[0].device)
+                               for run in SGD._contiguous_runs(group["params"])]
         except (_lib.BvcError, AttributeError, TypeError):
             return super()._check_inf_per_device(optimizer)
         per_device = {}
         L = _lib.lib()
-        for run in runs:
-            dev = run[0].device
+        for ptr, n, dev in ranges:
             if dev not in per_device:
                 per_device[dev] = torch.zeros((), dtype=torch.float32, device=dev)
-            n = sum(p.numel() for p in run)
             with torch.cuda.device(dev):
-                _lib.check(L.bvc_op_nonfinite_check(run[0].grad.data_ptr(), n, per_device[dev].data_ptr(),
-                                                    _lib.current_stream_ptr()), "bvc_op_nonfinite_check")
+                _lib.check(L.bvc_op_nonfinite_check(ptr, n, per_device[dev].data_ptr(), _lib.current_stream_ptr()), "bvc_op_nonfinite_check")
         if not per_device:
             per_device[_scale.device] = torch.zeros((), dtype=torch.float32, device=_scale.device)
         states[id(optimizer)]["found_inf_per_device"] = per_device

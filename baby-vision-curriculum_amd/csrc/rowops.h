@@ -49,6 +49,12 @@ int launch_adam_prep(float* state, double lr, double beta1, double beta2, const 
 int launch_adam_step(float* p, float* g, float* m, float* v, size_t n, double lr, double beta1, double beta2, double eps, double wd,
                      int decoupled, int maximize, const float* state, const float* grad_scale, const float* found_inf, int write_grad,
                      bf16_t* shadow, hipStream_t s);
+int launch_sgd_step_segments(float* p, float* g, float* buf, int64_t n, const int64_t* seg_start, const int* seg_group, const int* blk_seg,
+                             int nseg, const bvc_sgd_groups* groups, const float* grad_scale, const float* found_inf, int write_grad,
+                             bf16_t* shadow, hipStream_t s);
+int launch_adam_step_segments(float* p, float* g, float* m, float* v, int64_t n, const int64_t* seg_start, const int* seg_group,
+                              const int* blk_seg, int nseg, const bvc_adam_groups* groups, float* state, double* hyper_dev,
+                              const float* grad_scale, const float* found_inf, int write_grad, bf16_t* shadow, hipStream_t s);
 int launch_pad_heads(const bf16_t* wqkv, const float* bqkv, const bf16_t* wo, bf16_t* wqkv_p, float* bqkv_p, bf16_t* wo_p, int D, int H,
                      int hd, int hdp, hipStream_t s);
 int launch_unpad_head_grads(const float* gwqkv_p, const float* gbqkv_p, const float* gwo_p, float* gwqkv, float* gbqkv, float* gwo, int D,

@@ -858,6 +858,179 @@ __global__ void adam_step_kernel(float* __restrict__ p, float* __restrict__ g, f
     }
 }
 
+// ============================================================================ the same updates over a flat buffer with PARAMETER GROUPS
+// The reference's JEPA optimiser has four groups (pretraining/predictive/helper.py:123-147: encoder / predictor weights with weight
+// decay, their biases and 1-D tensors with weight_decay 0) and the flat layout interleaves weights and biases: a launch per run of
+// memory-adjacent parameters of one group would be ~9 launches per layer.  Here ONE launch covers the whole flat buffer: a static
+// table cuts it into segments (seg_start[s] .. seg_start[s + 1], ascending, element offsets) owned by group seg_group[s] (-1: no
+// group - frozen parameters, padding - left untouched), blk_seg[b] is the segment that holds element 1024 b (so that a thread
+// finds its segment in one or two steps), and the groups' hyper-parameters travel by value as kernel arguments (they change per
+// step under a schedule; the table does not).  A quad of elements inside one segment takes the vector path - the same arithmetic,
+// statement for statement, as sgd_step_kernel / adam_step_kernel -, a quad that straddles a boundary goes element by element.
+struct SgdGroupsDev {
+    float lr[BVC_OPT_MAX_GROUPS], wd[BVC_OPT_MAX_GROUPS], momentum[BVC_OPT_MAX_GROUPS], dampening[BVC_OPT_MAX_GROUPS];
+    int flags[BVC_OPT_MAX_GROUPS];      // 1 = nesterov, 2 = maximize, 4 = first step (buf = g)
+};
+struct AdamGroupsDev {
+    float omb1[BVC_OPT_MAX_GROUPS], beta2[BVC_OPT_MAX_GROUPS], omb2[BVC_OPT_MAX_GROUPS], eps[BVC_OPT_MAX_GROUPS], wd[BVC_OPT_MAX_GROUPS],
+        decay_mul[BVC_OPT_MAX_GROUPS];
+    int flags[BVC_OPT_MAX_GROUPS];      // 1 = decoupled (AdamW), 2 = maximize
+};
+
+// hyper-parameter of group `grp` out of a by-value table: a select chain (kernel arguments live in scalar registers and cannot be
+// indexed by a per-lane value without a trip through scratch)
+template <typename T>
+__device__ __forceinline__ T pick_group(const T (&tab)[BVC_OPT_MAX_GROUPS], int grp) {
+    T v = tab[0];
+#pragma unroll
+    for (int i = 1; i < BVC_OPT_MAX_GROUPS; ++i) v = grp == i ? tab[i] : v;
+    return v;
+}
+
+__device__ __forceinline__ int find_segment(const int64_t* __restrict__ seg_start, int s, int64_t i) {
+    while (seg_start[s + 1] <= i) ++s;
+    return s;
+}
+
+__global__ __launch_bounds__(256) void sgd_step_seg_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ buf, int64_t n,
+                                                           const int64_t* __restrict__ seg_start, const int* __restrict__ seg_group,
+                                                           const int* __restrict__ blk_seg, const SgdGroupsDev G,
+                                                           const float* __restrict__ grad_scale, const float* __restrict__ found_inf,
+                                                           int write_grad, bf16_t* __restrict__ shadow) {
+    if (found_inf && *found_inf != 0.f) return;
+    const float inv = grad_scale ? 1.f / *grad_scale : 1.f;
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= n) return;
+    int s = find_segment(seg_start, blk_seg[blockIdx.x], i);
+    if (i + 4 <= n && i + 4 <= seg_start[s + 1]) {
+        const int grp = seg_group[s];
+        if (grp < 0) return;
+        const float lr = pick_group(G.lr, grp), wd = pick_group(G.wd, grp), momentum = pick_group(G.momentum, grp),
+                    dampening = pick_group(G.dampening, grp);
+        const int fl = pick_group(G.flags, grp);
+        f32x4 pv = *reinterpret_cast<f32x4*>(p + i);
+        f32x4 gv = *reinterpret_cast<f32x4*>(g + i) * inv;
+        if (fl & 2) gv = -gv;
+        const f32x4 gu = gv;
+        if (wd != 0.f) gv += pv * wd;
+        f32x4 d = gv;
+        if (momentum != 0.f) {
+            f32x4 bv = (fl & 4) ? gv : *reinterpret_cast<f32x4*>(buf + i) * momentum + gv * (1.f - dampening);
+            *reinterpret_cast<f32x4*>(buf + i) = bv;
+            d = (fl & 1) ? gv + bv * momentum : bv;
+        }
+        const f32x4 pn = pv - d * lr;
+        *reinterpret_cast<f32x4*>(p + i) = pn;
+        if (shadow) *reinterpret_cast<uint2*>(shadow + i) = uint2{pack2bf(pn[0], pn[1]), pack2bf(pn[2], pn[3])};
+        if (write_grad) *reinterpret_cast<f32x4*>(g + i) = gu;
+    } else {
+        for (int64_t j = i; j < n && j < i + 4; ++j) {
+            s = find_segment(seg_start, s, j);
+            const int grp = seg_group[s];
+            if (grp < 0) continue;
+            const float lr = pick_group(G.lr, grp), wd = pick_group(G.wd, grp), momentum = pick_group(G.momentum, grp),
+                        dampening = pick_group(G.dampening, grp);
+            const int fl = pick_group(G.flags, grp);
+            float gv = g[j] * inv;
+            if (fl & 2) gv = -gv;
+            const float gu = gv;
+            if (wd != 0.f) gv += p[j] * wd;
+            float d = gv;
+            if (momentum != 0.f) {
+                const float bv = (fl & 4) ? gv : buf[j] * momentum + gv * (1.f - dampening);
+                buf[j] = bv;
+                d = (fl & 1) ? gv + bv * momentum : bv;
+            }
+            p[j] -= lr * d;
+            if (shadow) shadow[j] = f2bf(p[j]);
+            if (write_grad) g[j] = gu;
+        }
+    }
+}
+
+// state[3 grp + {0, 1, 2}] as adam_prep_kernel's state3, one thread per group
+__global__ void adam_prep_groups_kernel(float* __restrict__ state, int ngroups, const double* __restrict__ hyper /* [ngroups][3]: lr, beta1, beta2 */,
+                                        const float* __restrict__ found_inf) {
+    const int grp = threadIdx.x;
+    if (blockIdx.x != 0 || grp >= ngroups) return;
+    if (found_inf && *found_inf != 0.f) return;
+    const double lr = hyper[3 * grp], beta1 = hyper[3 * grp + 1], beta2 = hyper[3 * grp + 2];
+    const double step = (double)state[3 * grp] + 1.0;
+    state[3 * grp] = (float)step;
+    state[3 * grp + 1] = (float)(lr / (1.0 - pow(beta1, step)));
+    state[3 * grp + 2] = (float)sqrt(1.0 - pow(beta2, step));
+}
+
+__global__ __launch_bounds__(256) void adam_step_seg_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                                            int64_t n, const int64_t* __restrict__ seg_start, const int* __restrict__ seg_group,
+                                                            const int* __restrict__ blk_seg, const AdamGroupsDev G, const float* __restrict__ state,
+                                                            const float* __restrict__ grad_scale, const float* __restrict__ found_inf,
+                                                            int write_grad, bf16_t* __restrict__ shadow) {
+    if (found_inf && *found_inf != 0.f) return;
+    const float inv = grad_scale ? 1.f / *grad_scale : 1.f;
+    const int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i0 >= n) return;
+    int s = find_segment(seg_start, blk_seg[blockIdx.x], i0);
+    const bool vec = i0 + 4 <= n && i0 + 4 <= seg_start[s + 1];
+    const int cnt = i0 + 4 <= n ? 4 : (int)(n - i0);
+    float pv[4], gv[4], mv[4], vv[4], gu[4];
+    int grp4[4];
+    if (vec) {
+        *reinterpret_cast<f32x4*>(pv) = *reinterpret_cast<const f32x4*>(p + i0);
+        *reinterpret_cast<f32x4*>(gv) = *reinterpret_cast<const f32x4*>(g + i0);
+        *reinterpret_cast<f32x4*>(mv) = *reinterpret_cast<const f32x4*>(m + i0);
+        *reinterpret_cast<f32x4*>(vv) = *reinterpret_cast<const f32x4*>(v + i0);
+        const int grp = seg_group[s];
+        if (grp < 0) return;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) grp4[e] = grp;
+    } else {
+        for (int e = 0; e < 4; ++e) {
+            grp4[e] = -1;
+            pv[e] = gv[e] = mv[e] = vv[e] = 0.f;
+            if (e < cnt) {
+                s = find_segment(seg_start, s, i0 + e);
+                grp4[e] = seg_group[s];
+                pv[e] = p[i0 + e]; gv[e] = g[i0 + e]; mv[e] = m[i0 + e]; vv[e] = v[i0 + e];
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int grp = grp4[e] < 0 ? 0 : grp4[e];
+        const float omb1 = pick_group(G.omb1, grp), beta2 = pick_group(G.beta2, grp), omb2 = pick_group(G.omb2, grp),
+                    eps = pick_group(G.eps, grp), wd = pick_group(G.wd, grp), decay_mul = pick_group(G.decay_mul, grp);
+        const int fl = pick_group(G.flags, grp);
+        const float step_size = state[3 * grp + 1], bc2s = state[3 * grp + 2];
+        float gr = gv[e] * inv;
+        if (fl & 2) gr = -gr;
+        gu[e] = gr;
+        float pe = pv[e];
+        if (wd != 0.f) {
+            if (fl & 1) pe *= decay_mul; else gr += wd * pe;
+        }
+        const float me = mv[e] + omb1 * (gr - mv[e]);
+        const float ve = vv[e] * beta2 + omb2 * (gr * gr);
+        const float denom = sqrtf(ve) / bc2s + eps;
+        pv[e] = pe - step_size * (me / denom);
+        mv[e] = me; vv[e] = ve;
+    }
+    if (vec) {
+        *reinterpret_cast<f32x4*>(p + i0) = *reinterpret_cast<f32x4*>(pv);
+        *reinterpret_cast<f32x4*>(m + i0) = *reinterpret_cast<f32x4*>(mv);
+        *reinterpret_cast<f32x4*>(v + i0) = *reinterpret_cast<f32x4*>(vv);
+        if (shadow) *reinterpret_cast<uint2*>(shadow + i0) = uint2{pack2bf(pv[0], pv[1]), pack2bf(pv[2], pv[3])};
+        if (write_grad) *reinterpret_cast<f32x4*>(g + i0) = *reinterpret_cast<f32x4*>(gu);
+    } else {
+        for (int e = 0; e < cnt; ++e) {
+            if (grp4[e] < 0) continue;
+            p[i0 + e] = pv[e]; m[i0 + e] = mv[e]; v[i0 + e] = vv[e];
+            if (shadow) shadow[i0 + e] = f2bf(pv[e]);
+            if (write_grad) g[i0 + e] = gu[e];
+        }
+    }
+}
+
 // ============================================================================ zero-padded attention heads (hd -> hdp)
 // The JEPA predictor inherits the encoder's head COUNT (vision_transformer.py:447,463: num_heads=encoder.num_heads), so ViT-L
 // gives 16 heads of 24 dims - not an MFMA-friendly width.  The heads are run at 32 dims with zero padding: padded copies of
@@ -1180,6 +1353,61 @@ int launch_adam_step(float* p, float* g, float* m, float* v, size_t n, double lr
     hipLaunchKernelGGL(adam_step_kernel, dim3(blocks_for((n + 3) / 4)), dim3(256), 0, s, p, g, m, v, n, (float)(1.0 - beta1), (float)beta2,
                        (float)(1.0 - beta2), (float)eps, (float)wd, (float)(1.0 - lr * wd), decoupled, maximize, state, grad_scale,
                        found_inf, write_grad, shadow);
+    BVC_CHECK_HIP(hipGetLastError());
+    return BVC_OK;
+}
+
+static int check_segments(const char* who, int64_t n, const int64_t* seg_start, const int* seg_group, const int* blk_seg, int nseg, int ngroups) {
+    BVC_REQUIRE(seg_start && seg_group && blk_seg && nseg > 0, "%s: segment table missing", who);
+    BVC_REQUIRE(ngroups >= 1 && ngroups <= BVC_OPT_MAX_GROUPS, "%s: %d parameter groups (1..%d)", who, ngroups, BVC_OPT_MAX_GROUPS);
+    BVC_REQUIRE(n > 0, "%s: empty range", who);
+    return BVC_OK;
+}
+
+int launch_sgd_step_segments(float* p, float* g, float* buf, int64_t n, const int64_t* seg_start, const int* seg_group, const int* blk_seg,
+                             int nseg, const bvc_sgd_groups* gr, const float* grad_scale, const float* found_inf, int write_grad,
+                             bf16_t* shadow, hipStream_t s) {
+    BVC_REQUIRE(gr != nullptr, "sgd_step_segments: groups missing");
+    if (int rc = check_segments("sgd_step_segments", n, seg_start, seg_group, blk_seg, nseg, gr->ngroups)) return rc;
+    BVC_REQUIRE(((uintptr_t)p % 16 == 0) && ((uintptr_t)g % 16 == 0) && (buf == nullptr || (uintptr_t)buf % 16 == 0),
+                "sgd_step_segments: buffers must be 16-byte aligned");
+    BVC_REQUIRE(shadow == nullptr || (uintptr_t)shadow % 8 == 0, "sgd_step_segments: the bf16 shadow must be 8-byte aligned");
+    SgdGroupsDev G;
+    for (int i = 0; i < BVC_OPT_MAX_GROUPS; ++i) {
+        const int j = i < gr->ngroups ? i : 0;
+        BVC_REQUIRE(gr->momentum[j] == 0.f || buf != nullptr, "sgd_step_segments: momentum needs a buffer");
+        G.lr[i] = gr->lr[j]; G.wd[i] = gr->weight_decay[j]; G.momentum[i] = gr->momentum[j]; G.dampening[i] = gr->dampening[j];
+        G.flags[i] = (gr->nesterov[j] ? 1 : 0) | (gr->maximize[j] ? 2 : 0) | (gr->first_step[j] ? 4 : 0);
+    }
+    hipLaunchKernelGGL(sgd_step_seg_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, s, p, g, buf, n, seg_start, seg_group, blk_seg, G,
+                       grad_scale, found_inf, write_grad, shadow);
+    BVC_CHECK_HIP(hipGetLastError());
+    return BVC_OK;
+}
+
+int launch_adam_step_segments(float* p, float* g, float* m, float* v, int64_t n, const int64_t* seg_start, const int* seg_group,
+                              const int* blk_seg, int nseg, const bvc_adam_groups* gr, float* state, double* hyper_dev,
+                              const float* grad_scale, const float* found_inf, int write_grad, bf16_t* shadow, hipStream_t s) {
+    BVC_REQUIRE(gr != nullptr && state != nullptr && hyper_dev != nullptr, "adam_step_segments: groups / state missing");
+    if (int rc = check_segments("adam_step_segments", n, seg_start, seg_group, blk_seg, nseg, gr->ngroups)) return rc;
+    BVC_REQUIRE(((uintptr_t)p % 16 == 0) && ((uintptr_t)g % 16 == 0) && ((uintptr_t)m % 16 == 0) && ((uintptr_t)v % 16 == 0),
+                "adam_step_segments: buffers must be 16-byte aligned");
+    BVC_REQUIRE(shadow == nullptr || (uintptr_t)shadow % 8 == 0, "adam_step_segments: the bf16 shadow must be 8-byte aligned");
+    AdamGroupsDev G;
+    double hyper[3 * BVC_OPT_MAX_GROUPS];
+    for (int i = 0; i < BVC_OPT_MAX_GROUPS; ++i) {
+        const int j = i < gr->ngroups ? i : 0;
+        // hyper-parameters arrive as doubles (python floats) and are combined in double before the cast, as torch does
+        G.omb1[i] = (float)(1.0 - gr->beta1[j]); G.beta2[i] = (float)gr->beta2[j]; G.omb2[i] = (float)(1.0 - gr->beta2[j]);
+        G.eps[i] = (float)gr->eps[j]; G.wd[i] = (float)gr->weight_decay[j]; G.decay_mul[i] = (float)(1.0 - gr->lr[j] * gr->weight_decay[j]);
+        G.flags[i] = (gr->decoupled[j] ? 1 : 0) | (gr->maximize[j] ? 2 : 0);
+        hyper[3 * i] = gr->lr[j]; hyper[3 * i + 1] = gr->beta1[j]; hyper[3 * i + 2] = gr->beta2[j];
+    }
+    // the step-dependent scalars of every group in one tiny launch (lr, beta1, beta2 as doubles: 192 bytes through a pageable copy)
+    BVC_CHECK_HIP(hipMemcpyAsync(hyper_dev, hyper, sizeof(double) * 3 * gr->ngroups, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(adam_prep_groups_kernel, dim3(1), dim3(64), 0, s, state, gr->ngroups, hyper_dev, found_inf);
+    hipLaunchKernelGGL(adam_step_seg_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, s, p, g, m, v, n, seg_start, seg_group, blk_seg, G, state,
+                       grad_scale, found_inf, write_grad, shadow);
     BVC_CHECK_HIP(hipGetLastError());
     return BVC_OK;
 }

@@ -601,6 +601,21 @@ int bvc_op_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg
     return launch_adam_step(params, grads, exp_avg, exp_avg_sq, (size_t)n, lr, beta1, beta2, eps, weight_decay, decoupled, maximize,
                             state3, grad_scale, found_inf, write_unscaled_grads, (bf16_t*)bf16_shadow, (hipStream_t)stream);
 }
+int bvc_op_sgd_step_segments(float* params, float* grads, float* momentum_buf, int64_t n, const int64_t* seg_start, const int32_t* seg_group,
+                             const int32_t* blk_seg, int nseg, const bvc_sgd_groups* groups, const float* grad_scale, const float* found_inf,
+                             int write_unscaled_grads, void* bf16_shadow, void* stream) {
+    BVC_REQUIRE(params && grads && n >= 0, "op_sgd_step_segments: bad argument");
+    return launch_sgd_step_segments(params, grads, momentum_buf, n, seg_start, seg_group, blk_seg, nseg, groups, grad_scale, found_inf,
+                                    write_unscaled_grads, (bf16_t*)bf16_shadow, (hipStream_t)stream);
+}
+int bvc_op_adam_step_segments(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, const int64_t* seg_start,
+                              const int32_t* seg_group, const int32_t* blk_seg, int nseg, const bvc_adam_groups* groups, float* state,
+                              double* hyper_scratch, const float* grad_scale, const float* found_inf, int write_unscaled_grads,
+                              void* bf16_shadow, void* stream) {
+    BVC_REQUIRE(params && grads && exp_avg && exp_avg_sq && n >= 0, "op_adam_step_segments: bad argument");
+    return launch_adam_step_segments(params, grads, exp_avg, exp_avg_sq, n, seg_start, seg_group, blk_seg, nseg, groups, state, hyper_scratch,
+                                     grad_scale, found_inf, write_unscaled_grads, (bf16_t*)bf16_shadow, (hipStream_t)stream);
+}
 int bvc_videomae_shadow(bvc_ctx* c, int valid, void** shadow_bf16, int64_t* numel) {
     BVC_REQUIRE(c, "videomae_shadow: null context");
     if (shadow_bf16) *shadow_bf16 = c->wbf;

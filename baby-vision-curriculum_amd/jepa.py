@@ -380,6 +380,33 @@ def get_model(device, patch_size=16, tubelet_size=1, num_frames=1, model_name='v
     return encoder, predictor
 
 
+def _decay_split(module):
+    """(weights, no-decay tensors) of a module by the reference's rule (helper.py:124-140): a tensor is excluded from weight decay
+    when its name contains 'bias' or it is 1-D (LayerNorm scales; the frozen pos_embed and the mask token are 3-D and stay)."""
+    decay, plain = [], []
+    for n, p in module.named_parameters():
+        (plain if ("bias" in n or p.dim() == 1) else decay).append(p)
+    return decay, plain
+
+
+def init_opt(encoder, predictor, iterations_per_epoch, start_lr, ref_lr, momentum, warmup, num_epochs, wd=1e-6, final_wd=1e-6,
+             final_lr=0.0, use_bfloat16=False, ipe_scale=1.25):
+    """pretraining/predictive/helper.py:108-165 (called at pretrain_jepa.py:274): FOUR parameter groups - encoder weights,
+    predictor weights, then the encoder's and the predictor's biases / 1-D tensors with ``weight_decay`` 0 and the ``WD_exclude``
+    mark - under SGD(lr=ref_lr, weight_decay=wd, momentum, nesterov=True); the reference leaves both schedulers None and builds a
+    GradScaler when ``use_bfloat16``.  Here the optimiser is the fused one (two launches per step: one per flat buffer, whatever
+    the groups) and the scaler is the one whose inf check is a single read per flat gradient buffer."""
+    from . import amp, optim
+    enc_w, enc_b = _decay_split(encoder)
+    pred_w, pred_b = _decay_split(predictor)
+    groups = [{"params": enc_w}, {"params": pred_w},
+              {"params": enc_b, "WD_exclude": True, "weight_decay": 0},
+              {"params": pred_b, "WD_exclude": True, "weight_decay": 0}]
+    optimizer = optim.SGD(groups, lr=ref_lr, weight_decay=wd, momentum=momentum, nesterov=True)
+    scaler = amp.GradScaler("cuda") if use_bfloat16 else None
+    return optimizer, scaler, None, None
+
+
 # ----------------------------------------------------------------------------- fused pieces of train_step
 def select_targets(h, masks_pred, eps=1e-5):
     """forward_target's tail (pretrain_jepa.py:387-392) in one kernel: F.layer_norm(h, (D,)) without affine, the rows the

@@ -1,4 +1,12 @@
-"""Fused SGD / Adam / AdamW for flat parameter buffers (one HIP launch per contiguous run of parameters).
+"""Fused SGD / Adam / AdamW for flat parameter buffers: ONE HIP launch per flat module, whatever the parameter groups.
+
+Parameters that live in a flat module's buffer (flat.py) with their gradients in its flat gradient buffer are updated by one
+launch over the whole buffer: a static device table cuts it into segments owned by a parameter group (or by none: frozen
+parameters), the groups' hyper-parameters travel per call (``bvc_op_sgd_step_segments`` / ``bvc_op_adam_step_segments``,
+include/bvc.h).  The reference's JEPA optimiser (pretraining/predictive/helper.py:123-147: four groups, biases and 1-D tensors
+with ``weight_decay`` 0) thereby costs two launches - encoder buffer, predictor buffer - like a single group does.  Parameters
+outside any flat buffer (an ordinary ``nn.Linear`` head) take one launch per run of memory-adjacent parameters of a group.
+
 
 Same constructor and update rule as ``torch.optim.SGD`` (the reference builds
 ``torch.optim.SGD(xmodel.parameters(), lr, weight_decay, momentum, nesterov=True)`` at
@@ -16,6 +24,85 @@ from . import _lib
 from . import flat as _flat
 
 
+def _owner(p):
+    """The flat module whose buffer holds parameter `p` with its gradient at the same offset of the flat gradient buffer."""
+    if p.grad is None or not p.is_cuda:
+        return None
+    ptr = p.data_ptr()
+    for m in list(_flat._MODULES):
+        f, g = getattr(m, "_flat", None), getattr(m, "_flat_grad", None)
+        if f is None or g is None or not f.is_cuda:
+            continue
+        base = f.data_ptr()
+        if base <= ptr < base + 4 * f.numel() and p.grad.data_ptr() == g.data_ptr() + (ptr - base) and ptr + 4 * p.numel() <= base + 4 * f.numel():
+            return m
+    return None
+
+
+class _Plan:
+    """Segment table of one flat module for one optimiser: device arrays + the parameters per group, built once."""
+
+    def __init__(self, module, items):
+        # items: [(offset in elements, parameter, group index)]
+        items = sorted(items, key=lambda t: t[0])
+        self.module, self.items = module, items
+        f = module._flat
+        self.n = f.numel()
+        self.base, self.gbase = f.data_ptr(), module._flat_grad.data_ptr()
+        starts, groups, pos = [], [], 0
+        for off, prm, gi in items:
+            if off < pos:
+                raise _lib.BvcError("overlapping parameters in a flat buffer")
+            if off > pos:
+                starts.append(pos); groups.append(-1)
+            starts.append(off); groups.append(gi)
+            pos = off + prm.numel()
+        if pos < self.n:
+            starts.append(pos); groups.append(-1)
+        starts.append(self.n)
+        dev = f.device
+        self.nseg = len(groups)
+        self.seg_start = torch.tensor(starts, dtype=torch.int64, device=dev)
+        self.seg_group = torch.tensor(groups, dtype=torch.int32, device=dev)
+        nblk = (self.n + 1023) // 1024
+        firsts = torch.arange(nblk, dtype=torch.int64, device=dev) * 1024
+        self.blk_seg = (torch.searchsorted(self.seg_start, firsts, right=True) - 1).to(torch.int32)
+        self.state = None      # optimiser-specific flat state
+
+
+def _build_plans(param_groups):
+    """-> (plans, loose): plans = one _Plan per flat module that owns parameters of this optimiser; loose = {group index: [parameters
+    outside any flat buffer]}.  More groups than the table carries: everything is loose (a launch per adjacent run, as before)."""
+    loose, per_module = {}, {}
+    if len(param_groups) > _lib.OPT_MAX_GROUPS:
+        return [], {gi: [p for p in g["params"] if p.grad is not None] for gi, g in enumerate(param_groups)}
+    for gi, group in enumerate(param_groups):
+        for p in group["params"]:
+            if p.grad is None:
+                continue
+            if p.dtype != torch.float32 or p.grad.dtype != torch.float32 or not p.is_cuda:
+                raise _lib.BvcError("the bvc optimisers handle f32 CUDA parameters only")
+            m = _owner(p)
+            if m is None:
+                loose.setdefault(gi, []).append(p)
+            else:
+                per_module.setdefault(id(m), (m, []))[1].append(((p.data_ptr() - m._flat.data_ptr()) // 4, p, gi))
+    return [_Plan(m, items) for m, items in per_module.values()], loose
+
+
+def _plans_key(param_groups):
+    key = []
+    for g in param_groups:
+        ps = g["params"]
+        if not ps:
+            key.append(0)
+            continue
+        key.append((len(ps), ps[0].data_ptr(), ps[-1].data_ptr(),
+                    ps[0].grad.data_ptr() if ps[0].grad is not None else 0,
+                    ps[-1].grad.data_ptr() if ps[-1].grad is not None else 0))
+    return tuple(key)
+
+
 class SGD(torch.optim.Optimizer):
     _step_supports_amp_scaling = True
 
@@ -27,7 +114,32 @@ class SGD(torch.optim.Optimizer):
         defaults = dict(lr=lr, momentum=momentum, dampening=dampening, weight_decay=weight_decay, nesterov=nesterov,
                         maximize=maximize)
         super().__init__(params, defaults)
-        self._runs = {}   # group index -> (key, runs)
+        self._runs = {}   # group index -> (key, runs) for parameters outside flat buffers
+        self._plans = None   # (key, plans, loose)
+
+    def _get_plans(self):
+        key = _plans_key(self.param_groups)
+        if self._plans is None or self._plans[0] != key:
+            plans, loose = _build_plans(self.param_groups)
+            self._plans = (key, plans, loose)
+            self._runs = {}
+        return self._plans[1], self._plans[2]
+
+    def _plan_momentum(self, plan):
+        """One flat momentum buffer per flat module; the per-parameter ``momentum_buffer`` entries are views into it."""
+        if plan.state is None:
+            flat = torch.zeros(plan.n, dtype=torch.float32, device=plan.module._flat.device)
+            fresh = {}
+            for off, p, gi in plan.items:
+                st = self.state[p]
+                old = st.get("momentum_buffer")
+                if old is not None:   # e.g. after load_state_dict, or a run-wise buffer of an earlier layout
+                    flat[off:off + p.numel()].copy_(old.reshape(-1))
+                else:
+                    fresh[gi] = True
+                st["momentum_buffer"] = flat[off:off + p.numel()].view(p.shape)
+            plan.state = (flat, fresh)
+        return plan.state
 
     @staticmethod
     def _contiguous_runs(params):
@@ -48,8 +160,7 @@ class SGD(torch.optim.Optimizer):
             runs.append(cur)
         return runs
 
-    def _group_runs(self, gi, group):
-        ps = group["params"]
+    def _group_runs(self, gi, ps):
         key = (len(ps), ps[0].data_ptr(), ps[-1].data_ptr(),
                ps[0].grad.data_ptr() if ps[0].grad is not None else 0,
                ps[-1].grad.data_ptr() if ps[-1].grad is not None else 0)
@@ -91,8 +202,28 @@ class SGD(torch.optim.Optimizer):
         found_inf = getattr(self, "found_inf", None)
         L = _lib.lib()
         stream = _lib.current_stream_ptr()
-        for gi, group in enumerate(self.param_groups):
-            for run in self._group_runs(gi, group):
+        gs = grad_scale.data_ptr() if grad_scale is not None else None
+        fi = found_inf.data_ptr() if found_inf is not None else None
+        plans, loose = self._get_plans()
+        for plan in plans:
+            G = _lib.SgdGroupsC()
+            G.ngroups = len(self.param_groups)
+            need_buf = any(g["momentum"] != 0 for g in self.param_groups)
+            flat, fresh = self._plan_momentum(plan) if need_buf else (None, {})
+            for gi, g in enumerate(self.param_groups):
+                G.lr[gi], G.momentum[gi], G.dampening[gi], G.weight_decay[gi] = float(g["lr"]), float(g["momentum"]), float(g["dampening"]), float(g["weight_decay"])
+                G.nesterov[gi], G.maximize[gi] = int(g["nesterov"]), int(g["maximize"])
+                # torch's first step sets buf = g without dampening; only matters when dampening != 0
+                G.first_step[gi] = int(bool(fresh.get(gi)) and g["dampening"] != 0 and found_inf is None)
+            _lib.check(L.bvc_op_sgd_step_segments(
+                plan.base, plan.gbase, flat.data_ptr() if flat is not None else None, plan.n, plan.seg_start.data_ptr(),
+                plan.seg_group.data_ptr(), plan.blk_seg.data_ptr(), plan.nseg, ctypes.byref(G), gs, fi, 1,
+                _flat.shadow_for(plan.base, plan.n), stream), "bvc_op_sgd_step_segments")
+            if fresh:
+                plan.state = (flat, {})
+        for gi, ps in loose.items():
+            group = self.param_groups[gi]
+            for run in self._group_runs(gi, ps):
                 n = sum(p.numel() for p in run)
                 buf_ptr, first = None, 0
                 if group["momentum"] != 0:
@@ -102,10 +233,7 @@ class SGD(torch.optim.Optimizer):
                 _lib.check(L.bvc_op_sgd_step(
                     run[0].data_ptr(), run[0].grad.data_ptr(), buf_ptr, n, float(group["lr"]), float(group["momentum"]),
                     float(group["dampening"]), float(group["weight_decay"]), int(group["nesterov"]), first,
-                    int(group["maximize"]),
-                    grad_scale.data_ptr() if grad_scale is not None else None,
-                    found_inf.data_ptr() if found_inf is not None else None, 1,
-                    _flat.shadow_for(run[0].data_ptr(), n), stream), "bvc_op_sgd_step")
+                    int(group["maximize"]), gs, fi, 1, _flat.shadow_for(run[0].data_ptr(), n), stream), "bvc_op_sgd_step")
         return loss
 
     def state_dict(self):
@@ -118,8 +246,9 @@ class SGD(torch.optim.Optimizer):
 
 class Adam(torch.optim.Optimizer):
     """torch.optim.Adam's constructor, update rule and state layout (``step``, ``exp_avg``, ``exp_avg_sq`` per parameter;
-    the reference builds Adam / AdamW(betas=(0.9, 0.95)) at pretrain_videomae.py:190-193), as one HIP launch per contiguous
-    run of parameters.  The step count lives on the device so that a step skipped by GradScaler does not advance it."""
+    the reference builds Adam / AdamW(betas=(0.9, 0.95)) at pretrain_videomae.py:190-193), as one HIP launch per flat module (per
+    contiguous run for parameters outside flat buffers).  The step count lives on the device so that a step skipped by GradScaler
+    does not advance it."""
     _step_supports_amp_scaling = True
     _decoupled = False
 
@@ -130,9 +259,30 @@ class Adam(torch.optim.Optimizer):
             raise ValueError("invalid hyper-parameter")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=False, maximize=maximize))
         self._runs = {}
+        self._plans = None
 
     _contiguous_runs = staticmethod(SGD._contiguous_runs)
     _group_runs = SGD._group_runs
+    _get_plans = SGD._get_plans
+
+    def _plan_state(self, plan):
+        """Flat exp_avg / exp_avg_sq per flat module, the per-group step scalars (3 per group) and the f64 upload scratch."""
+        if plan.state is None:
+            dev = plan.module._flat.device
+            m, v = torch.zeros(plan.n, dtype=torch.float32, device=dev), torch.zeros(plan.n, dtype=torch.float32, device=dev)
+            state = torch.zeros(3 * _lib.OPT_MAX_GROUPS, dtype=torch.float32, device=dev)
+            hyper = torch.zeros(3 * _lib.OPT_MAX_GROUPS, dtype=torch.float64, device=dev)
+            for off, p, gi in plan.items:
+                st = self.state[p]
+                k = p.numel()
+                if "exp_avg" in st:    # after load_state_dict, or state of an earlier layout: adopt it (a group shares one step count)
+                    m[off:off + k].copy_(st["exp_avg"].reshape(-1))
+                    v[off:off + k].copy_(st["exp_avg_sq"].reshape(-1))
+                    state[3 * gi] = float(st["step"])
+                st["exp_avg"], st["exp_avg_sq"] = m[off:off + k].view(p.shape), v[off:off + k].view(p.shape)
+                st["step"] = state[3 * gi]
+            plan.state = (m, v, state, hyper)
+        return plan.state
 
     def _run_state(self, run):
         first = run[0]
@@ -171,9 +321,23 @@ class Adam(torch.optim.Optimizer):
         fi = found_inf.data_ptr() if found_inf is not None else None
         L = _lib.lib()
         stream = _lib.current_stream_ptr()
-        for gi, group in enumerate(self.param_groups):
+        plans, loose = self._get_plans()
+        for plan in plans:
+            m, v, state, hyper = self._plan_state(plan)
+            G = _lib.AdamGroupsC()
+            G.ngroups = len(self.param_groups)
+            for gi, g in enumerate(self.param_groups):
+                b1, b2 = g["betas"]
+                G.lr[gi], G.beta1[gi], G.beta2[gi], G.eps[gi], G.weight_decay[gi] = float(g["lr"]), float(b1), float(b2), float(g["eps"]), float(g["weight_decay"])
+                G.decoupled[gi], G.maximize[gi] = int(self._decoupled), int(g["maximize"])
+            _lib.check(L.bvc_op_adam_step_segments(
+                plan.base, plan.gbase, m.data_ptr(), v.data_ptr(), plan.n, plan.seg_start.data_ptr(), plan.seg_group.data_ptr(),
+                plan.blk_seg.data_ptr(), plan.nseg, ctypes.byref(G), state.data_ptr(), hyper.data_ptr(), gs, fi, 1,
+                _flat.shadow_for(plan.base, plan.n), stream), "bvc_op_adam_step_segments")
+        for gi, ps in loose.items():
+            group = self.param_groups[gi]
             b1, b2 = group["betas"]
-            for run in self._group_runs(gi, group):
+            for run in self._group_runs(gi, ps):
                 n = sum(p.numel() for p in run)
                 m, v, state3 = self._run_state(run)
                 _lib.check(L.bvc_op_adam_prepare(state3.data_ptr(), float(group["lr"]), float(b1), float(b2), fi, stream),

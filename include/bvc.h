@@ -298,6 +298,33 @@ int bvc_op_adam_prepare(float* state3, double lr, double beta1, double beta2, co
 int bvc_op_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, double lr, double beta1, double beta2,
                      double eps, double weight_decay, int decoupled, int maximize, const float* state3, const float* grad_scale,
                      const float* found_inf, int write_unscaled_grads, void* bf16_shadow, void* stream);
+/* The same updates for an optimiser with PARAMETER GROUPS over one flat buffer, as ONE launch (the reference's JEPA optimiser,
+ * pretraining/predictive/helper.py:123-147: four groups - encoder / predictor weights with weight decay, their biases and 1-D
+ * tensors with weight_decay 0 - over a layout that interleaves weights and biases).  The flat range [0, n) is cut into `nseg`
+ * segments: seg_start (device int64 [nseg + 1], ascending element offsets, seg_start[0] = 0, seg_start[nseg] = n), seg_group
+ * (device int32 [nseg]: the owning group, or -1 for elements no group owns - frozen parameters: left untouched), blk_seg (device
+ * int32 [ceil(n / 1024)]: the segment holding element 1024 b).  The groups' hyper-parameters are host values passed per call
+ * (schedules change them every step; the table is static).  Same arithmetic as bvc_op_sgd_step / bvc_op_adam_step per element. */
+#define BVC_OPT_MAX_GROUPS 8
+typedef struct bvc_sgd_groups {
+    int ngroups;
+    float lr[BVC_OPT_MAX_GROUPS], momentum[BVC_OPT_MAX_GROUPS], dampening[BVC_OPT_MAX_GROUPS], weight_decay[BVC_OPT_MAX_GROUPS];
+    int nesterov[BVC_OPT_MAX_GROUPS], first_step[BVC_OPT_MAX_GROUPS], maximize[BVC_OPT_MAX_GROUPS];
+} bvc_sgd_groups;
+typedef struct bvc_adam_groups {
+    int ngroups;
+    double lr[BVC_OPT_MAX_GROUPS], beta1[BVC_OPT_MAX_GROUPS], beta2[BVC_OPT_MAX_GROUPS], eps[BVC_OPT_MAX_GROUPS], weight_decay[BVC_OPT_MAX_GROUPS];
+    int decoupled[BVC_OPT_MAX_GROUPS], maximize[BVC_OPT_MAX_GROUPS];
+} bvc_adam_groups;
+int bvc_op_sgd_step_segments(float* params, float* grads, float* momentum_buf, int64_t n, const int64_t* seg_start, const int32_t* seg_group,
+                             const int32_t* blk_seg, int nseg, const bvc_sgd_groups* groups, const float* grad_scale, const float* found_inf,
+                             int write_unscaled_grads, void* bf16_shadow, void* stream);
+/* state = device f32 [3 ngroups] ({step count, lr / (1 - beta1^step), sqrt(1 - beta2^step)} per group, advanced inside the call
+ * unless *found_inf != 0); hyper_scratch = device f64 [3 ngroups] the call uploads lr / beta1 / beta2 into */
+int bvc_op_adam_step_segments(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, const int64_t* seg_start,
+                              const int32_t* seg_group, const int32_t* blk_seg, int nseg, const bvc_adam_groups* groups, float* state,
+                              double* hyper_scratch, const float* grad_scale, const float* found_inf, int write_unscaled_grads,
+                              void* bf16_shadow, void* stream);
 /* GradScaler's inf check (scaler.step at pretrain_videomae.py:313 -> torch.amp.GradScaler._check_inf_per_device) as one read-only
  * pass over a flat f32 range: *found_inf (device f32) is set to 1 if any element is Inf or NaN; it is never cleared here. */
 int bvc_op_nonfinite_check(const float* x, int64_t n, float* found_inf, void* stream);

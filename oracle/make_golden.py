@@ -361,11 +361,60 @@ def bf16_policy_fixture():
                    "probe_keys": list(vo.GRAD_PROBES), "torch": torch.__version__, "cases": cases}, f, indent=1)
 
 
+def b64_fixture():
+    """VideoMAE-base at 64 clips - the smallest batch at which the launcher picks the 256-clip benchmark's kernels by itself (every
+    encoder / decoder product passes gemm8's 45-GFLOP gate, the weight-gradient groups run split-K on 256 x 256 / 128 x 384 tiles):
+    transformers' own fp32 step (loss, the three grad_logger norms, the L2 norm of each of the 264 gradient tensors) and, next to it,
+    the probe norms of the oracle's bf16-OPERAND step under the build's policy (the reference for the build's OWN share of a
+    deviation).  One model at a time: each run holds 20-35 GB of activations in this 62 GB container."""
+    import gc
+    from oracle import videomae_oracle_bf16 as vb
+    name, cfg, batch, seed, wseed, ratio = "base_b64_s0", vo.BASE, 64, 0, 0, 0.9
+    params = vo.make_params(cfg, seed=wseed)
+    pixels, mask = vo.synthetic_batch(cfg, batch, seed, ratio)
+    model, ver = hf_model(cfg, params)
+    out = model(pixels, bool_masked_pos=mask)
+    out.loss.backward()
+    hgrads = {k: v.grad.detach().clone() for k, v in model.named_parameters()}
+    loss = float(out.loss)
+    del out, model
+    gc.collect()
+    fx = {
+        "case": name, "transformers": ver, "torch": torch.__version__,
+        "config": cfg.__dict__, "batch": batch, "seed": seed, "weight_seed": wseed, "mask_ratio": ratio,
+        "input": {"pixels": summarize(pixels), "mask_true": int(mask.sum())},
+        "loss": loss,
+        "grad_l2": {k: float(g.double().norm()) for k, g in hgrads.items()},
+        "grad_probes": {k: float(hgrads[k].double().norm()) for k in vo.GRAD_PROBES},
+    }
+    with open(os.path.join(GOLD, f"videomae_{name}.json"), "w") as f:
+        json.dump(fx, f, indent=1)
+    print(f"[{name}] transformers {ver}: loss {loss:.7f}, probes {[fx['grad_probes'][k] for k in vo.GRAD_PROBES]}")
+    fp32_probes = vb.probe_norms(hgrads)
+    del hgrads
+    gc.collect()
+    l, g = vb.step(cfg, params, pixels, mask, vb.BUILD)
+    entry = {"batch": batch, "seed": seed, "weight_seed": wseed, "mask_ratio": ratio,
+             "fp32": {"loss": loss, "probes": fp32_probes, "source": "transformers fp32 step (the oracle's equals it to 7e-7 at 2 / 16 clips)"},
+             "build": {"loss": float(l), "probes": vb.probe_norms(g)}}
+    print(f"[bf16 {name}] BUILD-policy probe deviations from fp32: "
+          f"{['%+.2e' % ((a - b) / b) for a, b in zip(entry['build']['probes'], fp32_probes)]}")
+    path = os.path.join(GOLD, "videomae_bf16_policy.json")
+    with open(path) as f:
+        doc = json.load(f)
+    doc["cases"][name] = entry
+    with open(path, "w") as f:
+        json.dump(doc, f, indent=1)
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     torch.manual_seed(0)
     if "--bf16-policy" in sys.argv:
         bf16_policy_fixture()
+        return
+    if "--b64" in sys.argv:            # the 64-clip whole-step pin (a few minutes of CPU, ~35 GB)
+        b64_fixture()
         return
     if "--full-size" in sys.argv:      # the BASELINE-size pins only (minutes of CPU): VideoMAE-base B=16, JEPA ViT-L, SimCLR 512 / 8192 rows
         one_case("base_b16_s0", vo.BASE, batch=16, seed=0, mask_ratio=0.9)

@@ -174,3 +174,88 @@ def test_uint8_frames_equal_normalised_f32_bitwise():
         a = enc(((u8.float() / 255.0 - 0.5) / 0.25).to(dev))
         b = enc(u8.to(dev))
     assert torch.equal(a, b)
+
+
+def test_reference_param_groups_match_torch_sgd_in_two_launches():
+    """The reference's JEPA optimiser (pretraining/predictive/helper.py:108-165, called at pretrain_jepa.py:274): four parameter
+    groups - encoder weights, predictor weights, encoder biases / 1-D tensors and the predictor's with weight_decay 0 - under
+    SGD-Nesterov.  bvc.jepa.init_opt builds exactly those groups; the fused step must (1) equal torch.optim.SGD on the same groups
+    over 4 steps to 2e-6, weight decay large enough to tell a decayed tensor from an excluded one, and (2) cost ONE launch per
+    flat buffer (encoder, predictor) - not one per run of memory-adjacent parameters of a group (~9 per layer)."""
+    cfg = jo.TINY
+    enc_p = jo.make_params(jo.encoder_shapes(cfg), cfg, 16)
+    pred_p = jo.make_params(jo.predictor_shapes(cfg), cfg, 17)
+    enc, pred, tgt = _modules(cfg, enc_p, pred_p, enc_p)
+    imgs, m_enc, m_pred = jo.synthetic_inputs(cfg, 4, 6, 8, 4)
+    x, me, mp = imgs.to(dev), [m.to(dev) for m in m_enc], [m.to(dev) for m in m_pred]
+    wd = 0.05
+    opt, scaler, sched, wd_sched = bvc.jepa.init_opt(enc, pred, iterations_per_epoch=10, start_lr=0.02, ref_lr=0.02, momentum=0.9, warmup=0,
+                                                     num_epochs=1, wd=wd, use_bfloat16=True)
+    assert sched is None and wd_sched is None and isinstance(scaler, bvc.amp.GradScaler)
+    assert len(opt.param_groups) == 4
+    assert [g["weight_decay"] for g in opt.param_groups] == [wd, wd, 0, 0] and all(g.get("WD_exclude") for g in opt.param_groups[2:])
+    # group membership by the reference's rule: 'bias' in the name or a 1-D tensor -> the excluded group
+    for mod, gw, gb in ((enc, 0, 2), (pred, 1, 3)):
+        for n, p in mod.named_parameters():
+            want = gb if ("bias" in n or p.dim() == 1) else gw
+            assert any(p is q for q in opt.param_groups[want]["params"]), n
+    # one real step to get .grad views into the flat gradient buffers
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        with torch.no_grad():
+            h = bvc.jepa.select_targets(tgt(x), mp)
+        loss = bvc.jepa.smooth_l1_loss(pred(enc(x, me), me, mp), h)
+    loss.backward()
+    # the torch reference on clones, same four groups in the same order
+    mine = [list(g["params"]) for g in opt.param_groups]
+    ref = [[torch.nn.Parameter(p.detach().clone(), requires_grad=p.requires_grad) for p in ps] for ps in mine]
+    ropt = torch.optim.SGD([{"params": ref[0]}, {"params": ref[1]}, {"params": ref[2], "weight_decay": 0}, {"params": ref[3], "weight_decay": 0}],
+                           lr=0.02, weight_decay=wd, momentum=0.9, nesterov=True, foreach=False)
+    calls = {"seg": 0, "run": 0}
+    L = bvc._lib.lib()
+    seg_fn, run_fn = L.bvc_op_sgd_step_segments, L.bvc_op_sgd_step
+
+    class _Count:
+        def __init__(self, fn, key):
+            self.fn, self.key = fn, key
+
+        def __call__(self, *a):
+            calls[self.key] += 1
+            return self.fn(*a)
+    L.bvc_op_sgd_step_segments, L.bvc_op_sgd_step = _Count(seg_fn, "seg"), _Count(run_fn, "run")
+    try:
+        gen = torch.Generator(device=dev).manual_seed(3)
+        for it in range(4):
+            for m in (enc, pred):
+                m.flat_grads().copy_(torch.randn(m.flat_grads().shape, device=dev, generator=gen) * 0.1)
+            for ps, rs in zip(mine, ref):
+                for p, r in zip(ps, rs):
+                    r.grad = None if p.grad is None else p.grad.detach().clone()
+            opt.param_groups[0]["lr"] = opt.param_groups[2]["lr"] = 0.02 * (1 + it)      # a schedule moves the hyper-parameters per step
+            ropt.param_groups[0]["lr"] = ropt.param_groups[2]["lr"] = 0.02 * (1 + it)
+            opt.step()
+            ropt.step()
+            torch.cuda.synchronize()
+            for ps, rs in zip(mine, ref):
+                for p, r in zip(ps, rs):
+                    torch.testing.assert_close(p.data, r.data, rtol=2e-6, atol=2e-7)
+    finally:
+        L.bvc_op_sgd_step_segments, L.bvc_op_sgd_step = seg_fn, run_fn
+    assert calls == {"seg": 8, "run": 0}, calls        # 4 steps x (encoder buffer + predictor buffer)
+    # the frozen positional tables sit inside the flat buffers and belong to no group: untouched
+    assert torch.equal(enc.state_dict()["pos_embed"].cpu(), enc_p["pos_embed"])
+    sd = opt.state_dict()
+    assert all(set(st) == {"momentum_buffer"} for st in sd["state"].values())
+    # and the whole reference loop body with the scaler: steps are taken (not skipped), the loss falls
+    opt.zero_grad()
+    losses = []
+    for it in range(4):
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            with torch.no_grad():
+                h = bvc.jepa.select_targets(tgt(x), mp)
+            loss = bvc.jepa.smooth_l1_loss(pred(enc(x, me), me, mp), h)
+        scaler.scale(loss).backward()
+        scaler.step(opt)
+        scaler.update()
+        opt.zero_grad()
+        losses.append(float(loss))
+    assert scaler.get_scale() == 65536.0 and losses[-1] < losses[0], (scaler.get_scale(), losses)

@@ -33,9 +33,10 @@ def jepa_leg(bvc, dev, model="vit_large", batch=16, nctx=100, npred=25, warmup=3
         p.requires_grad = False
     for m in (enc, pred, tgt):
         m._ensure_flat(dev)
-    opt = bvc.optim.SGD([{"params": [p for p in enc.parameters() if p.requires_grad]},
-                         {"params": [p for p in pred.parameters() if p.requires_grad]}], lr=0.1, momentum=0.9, nesterov=True, weight_decay=1e-6)
-    scaler = bvc.amp.GradScaler("cuda")
+    # the reference's optimiser (pretraining/predictive/helper.py:108-165 via pretrain_jepa.py:274): four groups, weight decay 1e-6 on the
+    # weights only, SGD-Nesterov, GradScaler
+    opt, scaler, _sched, _wd_sched = bvc.jepa.init_opt(enc, pred, iterations_per_epoch=1000, start_lr=0.1, ref_lr=0.1, momentum=0.9, warmup=0,
+                                                       num_epochs=1, wd=1e-6, use_bfloat16=True)
     B = batch
     g = torch.Generator().manual_seed(1)
     imgs = ((torch.randint(0, 256, (B, 2, 3, 224, 224), generator=g, dtype=torch.uint8).float() / 255 - 0.5) / 0.25).to(dev)

@@ -81,6 +81,8 @@ class GemmDesc(ctypes.Structure):
         ("rowtok", c_void_p), ("pos", c_void_p), ("labels", c_void_p), ("partial", c_void_p),
         ("rin", c_int), ("rout", c_int),
         ("rowsum", c_void_p),
+        ("ln_gamma", c_void_p), ("ln_beta", c_void_p), ("ln_mean", c_void_p), ("ln_rstd", c_void_p), ("ln_eps", c_float),
+        ("ln_x", c_void_p), ("ln_part", c_void_p), ("ln_dgamma", c_void_p), ("ln_dbeta", c_void_p),
     ]
 
 
@@ -208,7 +210,7 @@ def check(rc, what=""):
 
 
 def set_option(name, value):
-    """bvc_set_option (include/bvc.h): "gemm8" -1 / 0 / 1, "dw_overlap" 0 / 1.  Returns the previous value."""
+    """bvc_set_option (include/bvc.h): "gemm8" -1 / 0 / 1, "dw_overlap" 0 / 1, "row_ln" -1 / 0 / 1.  Returns the previous value."""
     old = lib().bvc_get_option(name.encode())
     check(lib().bvc_set_option(name.encode(), int(value)), "bvc_set_option")
     return old

@@ -6,7 +6,8 @@ import torch
 from . import _lib
 
 NT, NN, TN = 0, 1, 2
-EPI = dict(F32=0, BF16=1, GELU=2, RESID=3, POS=4, E2D=5, LOSS=6, DGELU=7, F32_BF16=8, RELU=9, DRELU=10, NCE=11, NCE_BWD=12)
+EPI = dict(F32=0, BF16=1, GELU=2, RESID=3, POS=4, E2D=5, LOSS=6, DGELU=7, F32_BF16=8, RELU=9, DRELU=10, NCE=11, NCE_BWD=12,
+           RESID_LN=13, DLN=14)
 
 
 def _p(t):
@@ -14,7 +15,8 @@ def _p(t):
 
 
 def gemm_desc(A, B, M, N, K, epi, C, ldc=None, lda=None, ldb=None, alpha=1.0, alpha_dev=None, split_k=1, C2=None, bias=None,
-              resid=None, aux=None, labels=None, partial=None, rowsum=None, rowtok=None, pos=None, rin=0, rout=0):
+              resid=None, aux=None, labels=None, partial=None, rowsum=None, rowtok=None, pos=None, rin=0, rout=0, ln_gamma=None,
+              ln_beta=None, ln_mean=None, ln_rstd=None, ln_eps=0.0, ln_x=None, ln_part=None, ln_dgamma=None, ln_dbeta=None):
     d = _lib.GemmDesc()
     d.A, d.B = A.data_ptr(), B.data_ptr()
     d.M, d.N, d.K = M, N, K
@@ -29,6 +31,9 @@ def gemm_desc(A, B, M, N, K, epi, C, ldc=None, lda=None, ldb=None, alpha=1.0, al
     d.ldaux = aux.shape[-1] if aux is not None else 0
     d.labels, d.partial, d.rowsum = _p(labels), _p(partial), _p(rowsum)
     d.rowtok, d.pos, d.rin, d.rout = _p(rowtok), _p(pos), rin, rout
+    # BVC_EPI_RESID_LN / BVC_EPI_DLN: the LayerNorm fused into a 384-wide product (include/bvc.h)
+    d.ln_gamma, d.ln_beta, d.ln_mean, d.ln_rstd, d.ln_eps = _p(ln_gamma), _p(ln_beta), _p(ln_mean), _p(ln_rstd), ln_eps
+    d.ln_x, d.ln_part, d.ln_dgamma, d.ln_dbeta = _p(ln_x), _p(ln_part), _p(ln_dgamma), _p(ln_dbeta)
     return d
 
 

@@ -25,7 +25,9 @@ enum GemmEpilogue {
     EPI_RELU = BVC_EPI_RELU,         // C bf16 = relu(v + bias)
     EPI_DRELU = BVC_EPI_DRELU,       // C bf16 = v * (aux > 0)
     EPI_NCE = BVC_EPI_NCE,           // SimCLR loss partials (no C): see gemm.hip
-    EPI_NCE_BWD = BVC_EPI_NCE_BWD    // C bf16 = d loss / d (cos/T)
+    EPI_NCE_BWD = BVC_EPI_NCE_BWD,   // C bf16 = d loss / d (cos/T)
+    EPI_RESID_LN = BVC_EPI_RESID_LN, // C f32 = resid + v + bias, C2 bf16 = LayerNorm(C) (N = 384: full rows in one tile; gemm8.hip only)
+    EPI_DLN = BVC_EPI_DLN            // LayerNorm backward fused into the dX product that feeds it (N = 384; gemm8.hip only)
 };
 
 // the public descriptor IS the internal problem record (include/bvc.h)
@@ -37,7 +39,9 @@ constexpr int kMaxGroup = 4;
 //   gemm8:      0 = the measured selection (pick_gemm8 / plan_dw), 1 = the 256-row persistent kernel for EVERY product it can take
 //               (whatever its size: how the tests run the bench's kernel set at oracle-sized batches), -1 = never
 //   dw_overlap: 1 = the grouped weight-gradient launch of a layer runs on the context's side stream (no gain measured; A/B only)
-struct Options { int gemm8 = 0; int dw_overlap = 0; };
+//   row_ln:     LayerNorm fused into the neighbouring 384-wide product (gemm8.hip EC 4 / 5): 0 = the measured selection, 1 = whenever
+//               the shapes allow, -1 = never (the separate ln_fwd / ln_bwd passes)
+struct Options { int gemm8 = 0; int dw_overlap = 0; int row_ln = 0; };
 Options& options();
 
 // bvc_op_gemm_kernel: while `on`, the launchers write the name of the kernel instantiation they would launch (as rocprofv3
@@ -53,5 +57,8 @@ int launch_gemm(const GemmProblem* probs, int nprob, GemmLayout layout, int tile
 // number of loss partials an EPI_LOSS problem writes with the tile config launch_gemm would pick
 int gemm_num_tiles(const GemmProblem& p, int tile_cfg);
 int gemm_pick_tile(const GemmProblem* probs, int nprob, int tile_cfg);
+bool gemm_row_ln_ok(int M, int N, int K);
+// scratch floats an EPI_DLN problem needs in ln_part (one [2][384] row per workgroup of the one-workgroup-per-CU grid)
+constexpr size_t kRowLnPartFloats = 512 * 2 * 384;
 
 }  // namespace bvc

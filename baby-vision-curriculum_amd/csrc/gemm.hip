@@ -454,6 +454,10 @@ static int tiles_for(const GemmProblem& p, int cfg) {
     return ((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn);
 }
 
+// Can the LayerNorm next to a Linear with N output columns ride in that product's epilogue (EPI_RESID_LN / EPI_DLN)?  Full rows in one
+// 128 x 384 tile, whole-row offsets inside 32 bits.
+bool gemm_row_ln_ok(int M, int N, int K) { return N == 384 && K % 64 == 0 && K >= 128 && M > 0 && (double)M * 1536.0 < 4294000000.0; }
+
 int gemm_pick_tile(const GemmProblem* probs, int nprob, int tile_cfg) {
     if (tile_cfg == 6 || tile_cfg == 7) return tile_cfg - 6;     // the persistent kernel: 128x128 / 128x64 tiles
     if (tile_cfg == 9) return 0;                                  // persistent 128x128 with deferred stores
@@ -632,6 +636,17 @@ int launch_gemm(const GemmProblem* probs, int nprob, GemmLayout layout, int tile
     BVC_REQUIRE(nprob >= 1 && nprob <= kMaxGroup, "launch_gemm: nprob %d out of range", nprob);
     static thread_local bool skip_g8 = false;      // set while an auto-picked gemm8 launch that turned the problem down is re-planned
     bool auto_g8 = false;
+    if (probs[0].epi == EPI_RESID_LN || probs[0].epi == EPI_DLN) {
+        // LayerNorm fused into a 384-wide product: exists on the full-row tile of gemm8.hip only (the caller asks gemm_row_ln_ok first)
+        const GemmProblem& p = probs[0];
+        BVC_REQUIRE(nprob == 1 && (tile_cfg < 0 || tile_cfg == 12), "launch_gemm: the LayerNorm epilogues take one problem on tile config 12");
+        BVC_REQUIRE(gemm_row_ln_ok(p.M, p.N, p.K) && p.ldc == p.N && p.split_k == 1 && p.a_bytes < 0x80000000u && p.b_bytes < 0x80000000u,
+                    "launch_gemm: the LayerNorm epilogues need N == ldc == 384, K %% 64 == 0, operands below 2 GiB (M=%d N=%d K=%d)", p.M, p.N, p.K);
+        BVC_REQUIRE(p.C && p.C2 && p.ln_mean && p.ln_rstd && p.ln_gamma, "launch_gemm: LayerNorm epilogue with a null output / statistic / scale");
+        if (p.epi == EPI_RESID_LN) BVC_REQUIRE(layout == GEMM_NT && p.resid && p.ln_beta, "launch_gemm: RESID_LN is an NT product with a residual and a LayerNorm bias");
+        if (p.epi == EPI_DLN) BVC_REQUIRE(layout == GEMM_NN && p.ln_x && p.ln_part && p.ln_dgamma && p.ln_dbeta, "launch_gemm: DLN is an NN product with the LayerNorm input, partial scratch and parameter gradients");
+        tile_cfg = 12;
+    }
     if (tile_cfg < 0 && stages < 0 && !skip_g8) {
         const int g8 = pick_gemm8(probs, nprob, layout);
         if (g8 > 0) { tile_cfg = g8; auto_g8 = true; }

@@ -29,12 +29,25 @@
 // decoder layer fill 71 % of the MFMA work they execute (38 tiles of 65536 outputs for 1.77 M outputs), on 128 x 384 tiles 100 %
 // (36 tiles of 49152).  Same stream, same phases: wave tile 64 x 96 (4 x 6 MFMA tiles, 12 MFMAs per phase), one A half and three
 // B halves per K tile (again 128 KiB of staging), groups of 3 + 1 + 3 + 1 LDS-DMA pieces.
+//
+// Round 5: the 128 x 384 geometry for k-contiguous A (NT / NN) with ROW epilogues (EC = 4 / 5).  The decoder and the JEPA predictor are
+// 384 wide, so a 128 x 384 tile holds COMPLETE rows of a Linear's output and the LayerNorm next to that Linear can run in its epilogue:
+//   EC = 4 (NT, proj / fc2):  v = alpha acc + bias + residual -> C (f32 residual stream); mean / rstd of every row (wave-local sums
+//     over the wave's 96 columns, Chan's combination of the four wave columns through 4 KiB of LDS, one barrier) and the bf16
+//     LayerNorm output (the NEXT product's A operand) -> C2: the separate ln_fwd pass (read 1.5 KB, write 0.75 KB per row) is gone;
+//   EC = 5 (NN, dX of fc1 / qkv):  g = alpha acc is d/d(LayerNorm output); the epilogue reads the LayerNorm's f32 input and the incoming
+//     residual gradient, reduces mean(g gamma) and mean(g gamma xhat) per row, writes dres += rstd (g gamma - s1 - xhat s2) in f32 and as
+//     the bf16 operand copy, and folds the dgamma / dbeta column sums (16-lane DPP reductions into wave-private LDS accumulators, one
+//     partial row per workgroup at kernel end): the separate ln_bwd pass (d(ln out) written and re-read, 3.8 KB read per row) is gone.
+// Same stream and phases as the 256-row tiles; a wave ROW takes the row tiles 32 q + 16 wm (q = phase), so that A piece 0 (rows 0-63)
+// is read in phases 0-1 and piece 1 in phases 2-3 by both wave rows - the freeing order the staging groups assume.
 #include <stdio.h>
 #include <stdlib.h>
 
 #include <type_traits>
 
 #include "gemm_tile.h"
+#include "rowops.h"
 
 namespace bvc {
 
@@ -66,6 +79,15 @@ __device__ __forceinline__ bf16x8 tr_frag(uint32_t region, uint32_t lane_base, u
     bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((AS3 bf16x4*)(size_t)a);
     bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((AS3 bf16x4*)(size_t)(a + 1024u));
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+// sum over the 16 lanes of a DPP row (lanes with equal l >> 4): four rotations, every lane ends with the full sum
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, false));   // row_ror:8
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xF, 0xF, false));   // row_ror:4
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xF, 0xF, false));   // row_ror:2
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xF, 0xF, false));   // row_ror:1
+    return v;
 }
 
 // unit id -> problem, tile, K range.  Uniform (kernel arguments and blockIdx only).
@@ -125,13 +147,17 @@ __device__ __forceinline__ void decode_unit(const GemmGroup& g, int uid, Unit& u
 template <int BM, int BN, bool AT, bool BT, int EC>
 __global__ __launch_bounds__(512, 1) void gemm8_kernel(const GemmGroup g, const int total_units) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    static_assert(BM == 256 || (BM == 128 && BN == 384 && AT && BT && EC == 2), "128-row tiles: the 128 x 384 weight-gradient geometry only");
+    static_assert(BM == 256 || (BM == 128 && BN == 384), "128-row tiles: the 128 x 384 geometry only");
     static_assert(BN == 256 || BN == 128 || (BN == 384 && BM == 128), "column tiles of 256 / 128, or 384 with 128 rows");
+    static_assert((EC >= 4) == (BM == 128 && !AT), "row epilogues (EC 4 / 5) are the k-contiguous-A instantiations of the 128 x 384 tile, and only they");
+    static_assert(BM == 256 || EC >= 4 || (AT && BT && EC == 2), "128 x 384 with transposed A: weight gradients");
+    static_assert(EC != 4 || !BT, "EC 4 (residual + LayerNorm forward) is an NT product");
     constexpr int A_BYTES = BM * 64 * 2, B_BYTES = BN * 64 * 2, TILE = A_BYTES + B_BYTES;
     constexpr int WMR = BM / 2;                          // rows of a wave row
     constexpr int WN = BN / 4, TN = WN / 16, TM = WMR / 16, TMH = TM / 2;
     constexpr int NB = BN / 64, NBH = BN / 128, NAH = BM / 128;
-    constexpr int n0c = AT ? NBH : (NB < 2 ? NB : 2), n1c = AT ? NAH : NB - n0c, n2c = AT ? NBH : 2, n3c = AT ? NAH : 2;
+    constexpr int n0c = AT ? NBH : (NB == 6 ? 3 : NB < 2 ? NB : 2), n1c = AT ? NAH : NB - n0c, n2c = AT ? NBH : BM / 128, n3c = AT ? NAH : BM / 128;
+    constexpr int RT = BM / 128;                         // k-contiguous A: row tiles of a wave per phase
     constexpr int KMAX = (n0c > 2 || n1c > 2 || n2c > 2 || n3c > 2) ? 3 : 2;      // most LDS-DMA pieces in one group
     constexpr int PT = n0c + n1c + n2c + n3c;          // LDS-DMA instructions per wave per K tile
     // Where a phase issues its group.  EARLY (default): in the read segment, after the fragment reads and before the counted wait -
@@ -145,6 +171,9 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const GemmGroup g, const 
 #else
     constexpr bool LATE = false;
 #endif
+    // row epilogues (EC 4 / 5), bytes past the two staging slots: per-column parameters (bias | gamma | beta, or gamma), 4 KiB of
+    // row-statistics exchange [128 rows][4 wave columns][2], and for EC 5 the wave-private dgamma / dbeta accumulators [8][2][96]
+    constexpr int PAR_BYTES = EC == 4 ? 3 * BN * 4 : EC == 5 ? BN * 4 : 0, STAT_OFF = PAR_BYTES, COL_OFF = STAT_OFF + 4096;
     constexpr int CPR = BN == 384 ? 8 : WN / 8;   // epilogue geometry: 8-column chunks per wave-tile row (unused by the 384-wide tile)
     constexpr int NSIDE = TM * (16 / (64 / CPR));  // 16-byte chunks (= bf16 store instructions per output) per lane and unit
     static_assert(PT + 2 * NSIDE < 64, "vmcnt is a 6-bit counter");
@@ -175,7 +204,13 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const GemmGroup g, const 
             u_hi = g.bal_units + ((J + 1) * g.bal_tiles) / I;
         }
     }
-    if (uid >= u_hi) return;       // uniform per workgroup, before any barrier
+    if (uid >= u_hi) {             // uniform per workgroup, before any barrier
+        if constexpr (EC == 5) {   // every workgroup of the grid owns one row of column partials
+            float* pr = g.prob[0].ln_part + (size_t)blockIdx.x * 2 * BN;
+            for (int i = tid; i < 2 * BN; i += 512) pr[i] = 0.f;
+        }
+        return;
+    }
     // experiments build (BVC_GEMM_DEBUG = 1024 + (n << 12)): every other workgroup of an XCD starts n x 3.4 us late.  All workgroups
     // walk units of the same length from the same start, so their epilogues - the only phase with store / side-input traffic - hit
     // the memory system together; a start offset persists for the whole launch and puts one half's epilogues under the other half's K loops.
@@ -270,8 +305,8 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const GemmGroup g, const 
         if constexpr (!AT) {
             if constexpr (GI == 0) { if constexpr (K < n0c) load_b(rb_, K); }
             else if constexpr (GI == 1) { if constexpr (K < n1c) load_b(rb_, n0c + K); }
-            else if constexpr (GI == 2) { if constexpr (K < 2) load_a(ra_, K == 0 ? 0 : 2); }
-            else { if constexpr (K < 2) load_a(ra_, K == 0 ? 1 : 3); }
+            else if constexpr (GI == 2) { if constexpr (K < n2c) load_a(ra_, BM == 256 ? (K == 0 ? 0 : 2) : 0); }
+            else { if constexpr (K < n3c) load_a(ra_, BM == 256 ? (K == 0 ? 1 : 3) : 1); }
         } else {       // k rows 0-31 of every B half, of every A half, then k rows 32-63 likewise (piece 2 h + (k >= 32) of half h)
             if constexpr (GI == 0) { if constexpr (K < NBH) load_b(rb_, 2 * K); }
             else if constexpr (GI == 1) { if constexpr (K < NAH) load_a(ra_, 2 * K); }
@@ -307,6 +342,26 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const GemmGroup g, const 
         AS3 float* lbias = (AS3 float*)((AS3 char*)smem + 2 * TILE);
         const int npad = ((p0.N + BN - 1) / BN) * BN;
         for (int i = tid; i < npad; i += 512) lbias[i] = (p0.bias && i < p0.N) ? p0.bias[i] : 0.f;
+        __syncthreads();
+    }
+    if constexpr (EC == 4 || EC == 5) {
+        // per-column parameters of the (single) problem into LDS; the column accumulators of EC 5 start at zero.  Plain loads,
+        // waited for right here, before any LDS-DMA is in flight.
+        const GemmProblem& p0 = g.prob[0];
+        AS3 float* lpar = (AS3 float*)((AS3 char*)smem + 2 * TILE);
+        for (int i = tid; i < BN; i += 512) {
+            if constexpr (EC == 4) {
+                lpar[i] = p0.bias ? p0.bias[i] : 0.f;
+                lpar[BN + i] = p0.ln_gamma[i];
+                lpar[2 * BN + i] = p0.ln_beta[i];
+            } else {
+                lpar[i] = p0.ln_gamma[i];
+            }
+        }
+        if constexpr (EC == 5) {
+            AS3 float* lcol = (AS3 float*)((AS3 char*)smem + 2 * TILE + COL_OFF);
+            for (int i = tid; i < 8 * 2 * WN; i += 512) lcol[i] = 0.f;
+        }
         __syncthreads();
     }
     // ------------------------------------------------------------------ prologue: K tile 0 and groups 0, 1 of K tile 1
@@ -349,7 +404,7 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const GemmGroup g, const 
                     constexpr int q = decltype(q_)::value;
                     __builtin_amdgcn_sched_barrier(0);
 #ifdef BVC_G8_DMA_FIRST      // measured alternative (profiles/r03_f_gemm8_loop_variants.txt): the phase's LDS-DMA pieces ahead of its fragment reads
-                    if constexpr (!LATE) { stage_phase(q_, I0{}, cur, oth); stage_phase(q_, I1{}, cur, oth); }
+                    if constexpr (!LATE) { stage_phase(q_, I0{}, cur, oth); stage_phase(q_, I1{}, cur, oth); if constexpr (KMAX == 3) stage_phase(q_, I2{}, cur, oth); }
 #endif
                     uint32_t sw = tr_swz;
                     if constexpr (BT && q == 0) asm volatile("" : "+v"(sw));
@@ -361,13 +416,14 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const GemmGroup g, const 
                                 bfr[ks][j] = BT ? tr_frag(lds_base + (uint32_t)(cur - smem) + b_region(j), tr_base, sw, b_chunk16(j), ks)
                                                 : read_frag<BN, false>(lb, wn * WN + 16 * j, ks, lane);
                     }
-                    bf16x8 af[2][2];
+                    bf16x8 af[2][RT];
 #pragma unroll
                     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-                        for (int ii = 0; ii < 2; ++ii) af[ks][ii] = read_frag<256, false>(la, wm * WMR + 16 * (2 * q + ii), ks, lane);
+                        for (int ii = 0; ii < RT; ++ii)
+                            af[ks][ii] = read_frag<256, false>(la, BM == 256 ? wm * WMR + 16 * (2 * q + ii) : 32 * q + 16 * wm, ks, lane);
 #ifndef BVC_G8_DMA_FIRST
-                    if constexpr (!LATE) { stage_phase(q_, I0{}, cur, oth); stage_phase(q_, I1{}, cur, oth); }
+                    if constexpr (!LATE) { stage_phase(q_, I0{}, cur, oth); stage_phase(q_, I1{}, cur, oth); if constexpr (KMAX == 3) stage_phase(q_, I2{}, cur, oth); }
 #endif
                     if constexpr (q == 1) {
                         if (after_epi == 0) wait_vmcnt<W1>();
@@ -378,11 +434,11 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const GemmGroup g, const 
                     asm volatile("s_barrier" ::: "memory");   // fragment reads are builtins: hipcc places counted lgkmcnt waits in front of the MFMAs that use them
                     __builtin_amdgcn_sched_barrier(0);
                     __builtin_amdgcn_s_setprio(1);
-                    constexpr int NM = 4 * TN;       // MFMAs of the phase: the two LDS-DMA loads go after the first and the second quarter
+                    constexpr int NM = 2 * RT * TN;       // MFMAs of the phase: the two LDS-DMA loads go after the first and the second quarter
 #pragma unroll
                     for (int t = 0; t < NM; ++t) {
-                        const int ks = t / (2 * TN), ii = (t / TN) & 1, j = t % TN;
-                        acc[2 * q + ii][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ks][j], af[ks][ii], acc[2 * q + ii][j], 0, 0, 0);
+                        const int ks = t / (RT * TN), ii = (t / TN) % RT, j = t % TN;
+                        acc[RT * q + ii][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ks][j], af[ks][ii], acc[RT * q + ii][j], 0, 0, 0);
                         if constexpr (LATE) {
                             if (t == NM / 4 - 1) stage_phase(q_, I0{}, cur, oth);
                             if (t == NM / 2 - 1) stage_phase(q_, I1{}, cur, oth);
@@ -559,6 +615,181 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const GemmGroup g, const 
                 }
             }
             nstores = two_out ? 2 * NSIDE : NSIDE;
+        } else if constexpr (EC == 4) {
+            // ---- residual + LayerNorm forward on complete rows (N == ldc == BN).  Lane l holds, of row tile i, row 32 i + 16 wm + (l & 15)
+            // and the 4 columns wn 96 + 16 j + 4 (l >> 4) .. + 3 of each of the 6 column tiles j.  Descriptors carry the exact extent
+            // M x 384 elements: a row past M starts past it and every access to it is dropped (whole rows, no column test).
+            // Row tile by row tile, the residual rows of tile i + 1 in flight while tile i is finished (24 registers each: all four at
+            // once next to the accumulators made hipcc spill lane constants of the K loop into scratch).
+            const uint32_t ext = (uint32_t)Mrows * (uint32_t)(BN * 4);
+            const __amdgpu_buffer_rsrc_t rres = make_rsrc(p.resid, ext), rc = make_rsrc(p.C, ext), rc2 = make_rsrc(p.C2, ext / 2);
+            const __amdgpu_buffer_rsrc_t rmu = make_rsrc(p.ln_mean, (uint32_t)Mrows * 4u), rrs = make_rsrc(p.ln_rstd, (uint32_t)Mrows * 4u);
+            const AS3 float* lpar = (const AS3 float*)((AS3 char*)smem + 2 * TILE);
+            AS3 float* lstat = (AS3 float*)((AS3 char*)smem + 2 * TILE + STAT_OFF);
+            const int q4 = lane >> 4, r16 = lane & 15;
+            const int cw = wn * WN + 4 * q4;
+            const float eps = p.ln_eps;
+            const uint32_t obase = (uint32_t)(m0 + 16 * wm + r16) * (uint32_t)(BN * 4) + (uint32_t)cw * 4u;     // row tile i: + i * 32 rows
+            f32x4 rs[2][TN];
+            auto issue = [&](auto i_) {
+                constexpr int i = decltype(i_)::value;
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    rs[i & 1][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rres, obase + (uint32_t)(i * 32 * BN * 4 + 64 * j), 0, 0));
+            };
+            auto tile = [&](auto i_) {
+                constexpr int i = decltype(i_)::value;
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (i + 1 < TM) issue(std::integral_constant<int, i + 1>{});
+                __builtin_amdgcn_sched_barrier(0);
+                float sum = 0.f;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const f32x4 bj = *reinterpret_cast<const AS3 f32x4*>(lpar + cw + 16 * j);
+                    acc[i][j] = (acc[i][j] * alpha + bj) + rs[i & 1][j];
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][j]), rc, obase + (uint32_t)(i * 32 * BN * 4 + 64 * j), 0, BVC_G8_ST_AUX);
+                    sum += (acc[i][j][0] + acc[i][j][1]) + (acc[i][j][2] + acc[i][j][3]);
+                }
+                // statistics of the wave's 96 columns of this row: sum, and the squares about the wave's own mean (Chan's form: the four
+                // wave columns combine without cancellation)
+                sum += __shfl_xor(sum, 16, 64);
+                sum += __shfl_xor(sum, 32, 64);
+                const float mw = sum * (1.f / WN);
+                float sq = 0.f;
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { const float d = acc[i][j][e] - mw; sq += d * d; }
+                sq += __shfl_xor(sq, 16, 64);
+                sq += __shfl_xor(sq, 32, 64);
+                if (q4 == 0) *reinterpret_cast<AS3 f32x2*>(lstat + ((wm * 64 + 16 * i + r16) * 4 + wn) * 2) = f32x2{sum, sq};
+            };
+            issue(I0{});
+            wait_vmcnt<0>();      // one drain: the first residual rows and the next unit's prefetched K tiles (see the f32 class below)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(rs[0][j]));
+            tile(I0{}); tile(I1{}); tile(I2{}); tile(I3{});
+            // the four waves of a wave row run in step (the stagger is between wave rows): one barrier orders their exchange
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                asm volatile("" ::: "memory");     // (keeps the parameter reads below per row tile: hoisted, they are 48 live registers)
+                const AS3 f32x4* sp = reinterpret_cast<const AS3 f32x4*>(lstat + (wm * 64 + 16 * i + r16) * 8);
+                const f32x4 a = sp[0], b = sp[1];          // {sum, sq} of wave columns 0, 1 | 2, 3
+                const float mean = ((a[0] + a[2]) + (b[0] + b[2])) * (1.f / BN);
+                const float d0 = a[0] * (1.f / WN) - mean, d1 = a[2] * (1.f / WN) - mean, d2 = b[0] * (1.f / WN) - mean, d3 = b[2] * (1.f / WN) - mean;
+                const float m2 = ((a[1] + a[3]) + (b[1] + b[3])) + (float)WN * ((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3));
+                const float rstd = rsqrtf(m2 * (1.f / BN) + eps);
+                const int m = m0 + 32 * i + 16 * wm + r16;
+                if (wn == 0 && q4 == 0) {
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(mean), rmu, (uint32_t)m * 4u, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(rstd), rrs, (uint32_t)m * 4u, 0, 0);
+                }
+                // bf16 LayerNorm output, 16 bytes per lane after the v_permlane16_swap of a column-tile pair (as the bf16 class above)
+                const uint32_t o2 = ((uint32_t)m * (uint32_t)BN + (uint32_t)(wn * WN + 16 * (q4 & 1) + 8 * (q4 >> 1))) * 2u;
+#pragma unroll
+                for (int jp = 0; jp < TN / 2; ++jp) {
+                    const f32x4 ga = *reinterpret_cast<const AS3 f32x4*>(lpar + BN + cw + 32 * jp), gb = *reinterpret_cast<const AS3 f32x4*>(lpar + BN + cw + 32 * jp + 16);
+                    const f32x4 ba = *reinterpret_cast<const AS3 f32x4*>(lpar + 2 * BN + cw + 32 * jp), bb = *reinterpret_cast<const AS3 f32x4*>(lpar + 2 * BN + cw + 32 * jp + 16);
+                    const f32x4 ya = ((acc[i][2 * jp] - mean) * rstd) * ga + ba;
+                    const f32x4 yb = ((acc[i][2 * jp + 1] - mean) * rstd) * gb + bb;
+                    const uint32_t a0 = pack2bf(ya[0], ya[1]), a1 = pack2bf(ya[2], ya[3]), b0 = pack2bf(yb[0], yb[1]), b1 = pack2bf(yb[2], yb[3]);
+                    const auto s0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
+                    const auto s1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
+                    __builtin_amdgcn_raw_buffer_store_b128(u32x4{s0[0], s1[0], s0[1], s1[1]}, rc2, o2 + 64u * jp, 0, BVC_G8_ST_AUX);
+                }
+            }
+        } else if constexpr (EC == 5) {
+            // ---- LayerNorm backward on complete rows: acc = g = d/d(LayerNorm output).  Row tile by row tile; the LayerNorm input rows and
+            // the incoming residual gradient of tile i + 1 are in flight while tile i is reduced, exchanged and written.
+            const uint32_t ext = (uint32_t)Mrows * (uint32_t)(BN * 4);
+            const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.ln_x, ext), rd = make_rsrc(p.C, ext), rc2 = make_rsrc(p.C2, ext / 2);
+            const __amdgpu_buffer_rsrc_t rmu = make_rsrc(p.ln_mean, (uint32_t)Mrows * 4u), rrs = make_rsrc(p.ln_rstd, (uint32_t)Mrows * 4u);
+            const AS3 float* lpar = (const AS3 float*)((AS3 char*)smem + 2 * TILE);
+            AS3 float* lstat = (AS3 float*)((AS3 char*)smem + 2 * TILE + STAT_OFF);
+            AS3 float* lcol = (AS3 float*)((AS3 char*)smem + 2 * TILE + COL_OFF) + wave * 2 * WN;     // this wave's [dgamma | dbeta][96]
+            const int q4 = lane >> 4, r16 = lane & 15;
+            const int cw = wn * WN + 4 * q4;
+            const int mrow = m0 + 16 * wm + r16;                                                              // row tile i: + 32 i
+            const uint32_t obase = (uint32_t)mrow * (uint32_t)(BN * 4) + (uint32_t)cw * 4u;
+            const uint32_t o2base = ((uint32_t)mrow * (uint32_t)BN + (uint32_t)(wn * WN + 16 * (q4 & 1) + 8 * (q4 >> 1))) * 2u;
+            // (the residual-gradient rows of a tile are fetched at the START of that tile - they are consumed after its exchange - and only the
+            //  LayerNorm input rows one tile ahead: with both one tile ahead hipcc spilled lane constants of the K loop into scratch)
+            f32x4 xr[2][TN], dr[TN];
+            float mu[2], rsd[2];
+            auto issue = [&](auto i_) {
+                constexpr int i = decltype(i_)::value;
+                mu[i & 1] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rmu, (uint32_t)(mrow + 32 * i) * 4u, 0, 0));
+                rsd[i & 1] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rrs, (uint32_t)(mrow + 32 * i) * 4u, 0, 0));
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    xr[i & 1][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, obase + (uint32_t)(i * 32 * BN * 4 + 64 * j), 0, 0));
+            };
+            auto tile = [&](auto i_) {
+                constexpr int i = decltype(i_)::value, b = i & 1;
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    dr[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rd, obase + (uint32_t)(i * 32 * BN * 4 + 64 * j), 0, 0));
+                if constexpr (i + 1 < TM) issue(std::integral_constant<int, i + 1>{});
+                __builtin_amdgcn_sched_barrier(0);
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const f32x4 gam = *reinterpret_cast<const AS3 f32x4*>(lpar + cw + 16 * j);
+                    const f32x4 gv = acc[i][j] * alpha;
+                    const f32x4 xh = (xr[b][j] - mu[b]) * rsd[b];
+                    const f32x4 gg = gv * gam;
+                    f32x4 tg = gv * xh, tb = gv;
+                    s1 += (gg[0] + gg[1]) + (gg[2] + gg[3]);
+                    const f32x4 gx = gg * xh;
+                    s2 += (gx[0] + gx[1]) + (gx[2] + gx[3]);
+                    xr[b][j] = xh;
+                    acc[i][j] = gg;
+                    // column sums over the 16 rows the lanes of a DPP row hold (rotations: every lane ends with the full sum), then the
+                    // four lanes with (l & 15) == 0 add their 4 columns into the wave's accumulators in LDS
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        tg[e] = row16_sum(tg[e]);
+                        tb[e] = row16_sum(tb[e]);
+                    }
+                    if (r16 == 0) {
+                        AS3 f32x4* cg = reinterpret_cast<AS3 f32x4*>(lcol + 16 * j + 4 * q4);
+                        AS3 f32x4* cb = reinterpret_cast<AS3 f32x4*>(lcol + WN + 16 * j + 4 * q4);
+                        *cg = *cg + tg;
+                        *cb = *cb + tb;
+                    }
+                }
+                s1 += __shfl_xor(s1, 16, 64);
+                s1 += __shfl_xor(s1, 32, 64);
+                s2 += __shfl_xor(s2, 16, 64);
+                s2 += __shfl_xor(s2, 32, 64);
+                if (q4 == 0) *reinterpret_cast<AS3 f32x2*>(lstat + ((wm * 64 + 16 * i + r16) * 4 + wn) * 2) = f32x2{s1, s2};
+                // the four waves of a wave row run in step (the stagger is between wave rows): one barrier orders their exchange
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                const AS3 f32x4* sp = reinterpret_cast<const AS3 f32x4*>(lstat + (wm * 64 + 16 * i + r16) * 8);
+                const f32x4 sa = sp[0], sb = sp[1];
+                const float c1 = ((sa[0] + sa[2]) + (sb[0] + sb[2])) * (1.f / BN), c2 = ((sa[1] + sa[3]) + (sb[1] + sb[3])) * (1.f / BN);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc[i][j] = ((acc[i][j] - c1) - xr[b][j] * c2) * rsd[b] + dr[j];
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][j]), rd, obase + (uint32_t)(i * 32 * BN * 4 + 64 * j), 0, BVC_G8_ST_AUX);
+                }
+#pragma unroll
+                for (int jp = 0; jp < TN / 2; ++jp) {
+                    const f32x4 ya = acc[i][2 * jp], yb = acc[i][2 * jp + 1];
+                    const uint32_t a0 = pack2bf(ya[0], ya[1]), a1 = pack2bf(ya[2], ya[3]), b0 = pack2bf(yb[0], yb[1]), b1 = pack2bf(yb[2], yb[3]);
+                    const auto w0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
+                    const auto w1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
+                    __builtin_amdgcn_raw_buffer_store_b128(u32x4{w0[0], w1[0], w0[1], w1[1]}, rc2, o2base + (uint32_t)(i * 32 * BN * 2 + 64 * jp), 0, BVC_G8_ST_AUX);
+                }
+            };
+            issue(I0{});
+            wait_vmcnt<0>();         // the first row tile's rows and the next unit's prefetched K tiles
+            asm volatile("" : "+v"(mu[0]), "+v"(rsd[0]));
+#pragma unroll
+            for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(xr[0][j]));
+            tile(I0{}); tile(I1{}); tile(I2{}); tile(I3{});
         } else if constexpr (BN == 384) {
             // 128 x 384 weight-gradient tile: the wave's 64 x 96 outputs leave through 16 rows x 48 columns of parking at a time (two
             // passes per row tile), one dword per lane - runs of 64 consecutive floats of the row-major [16][48] image, i.e. 64-byte
@@ -776,13 +1007,23 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const GemmGroup g, const 
         decode_unit<BM, BN>(g, uid, cu);
         // (atomics and the 384-wide tile's dword stores queue behind the prefetch like any store: the plain counted wait of the next
         //  K tile then waits for them as well - once per unit, conservative and exact)
-        after_epi = ((EC == 2 && atomic) || BN == 384) ? 0 : EC == 0 ? nstores : -1;
+        after_epi = EC >= 4 ? -1 : ((EC == 2 && atomic) || BN == 384) ? 0 : EC == 0 ? nstores : -1;
     }
     // drain the out-of-range tail of the stream, then pay back the stagger barrier
     wait_vmcnt<0>();
 #ifndef BVC_G8_NO_STAGGER
     if (wm == 0) asm volatile("s_barrier" ::: "memory");
 #endif
+    if constexpr (EC == 5) {
+        // one row of dgamma / dbeta partials per workgroup: the two wave rows' accumulators of every wave column, fixed order
+        __syncthreads();
+        const AS3 float* lcol = (const AS3 float*)((AS3 char*)smem + 2 * TILE + COL_OFF);
+        float* pr = g.prob[0].ln_part + (size_t)blockIdx.x * 2 * BN;
+        for (int c = tid; c < 2 * BN; c += 512) {
+            const int which = c / BN, col = c % BN, w = col / WN, cc = col % WN;
+            pr[c] = lcol[(w * 2 + which) * WN + cc] + lcol[((4 + w) * 2 + which) * WN + cc];
+        }
+    }
 }
 
 // ------------------------------------------------------------------ host side
@@ -831,7 +1072,8 @@ template <int BM, int BN, bool AT, bool BT, int EC>
 static int launch_gemm8_one(const GemmGroup& g_in, int total, hipStream_t stream) {
     // two K-tile slots + the epilogue region: 16 parked rows per wave (classes 1-3; 16 x 48 for the 384-wide tile) or the bias
     // copy of class 0 (32 KiB: N <= 8192)
-    constexpr size_t lds = 2 * (size_t)(BM + BN) * 64 * 2 + (EC == 0 ? (size_t)32768 : BN == 384 ? (size_t)8 * 16 * 48 * 4 : (size_t)8 * 16 * (BN / 4) * 4);
+    constexpr size_t lds = 2 * (size_t)(BM + BN) * 64 * 2 + (EC == 0 ? (size_t)32768 : EC == 4 ? (size_t)(3 * BN * 4 + 4096) : EC == 5 ? (size_t)(BN * 4 + 4096 + 8 * 2 * (BN / 4) * 4) :
+                                                              BN == 384 ? (size_t)8 * 16 * 48 * 4 : (size_t)8 * 16 * (BN / 4) * 4);
     static_assert(lds <= 160 * 1024, "LDS per CU");
     if (dry_run().on) {
         snprintf(dry_run().name, sizeof(dry_run().name), "bvc::gemm8_kernel<%d, %d, %s, %s, %d>", BM, BN, AT ? "true" : "false", BT ? "true" : "false", EC);
@@ -851,11 +1093,15 @@ static int launch_gemm8_one(const GemmGroup& g_in, int total, hipStream_t stream
     }
     hipLaunchKernelGGL((gemm8_kernel<BM, BN, AT, BT, EC>), dim3(grid), dim3(512), lds, stream, g, total);
     BVC_CHECK_HIP(hipGetLastError());
+    if constexpr (EC == 5)      // every workgroup of the grid left one row of dgamma / dbeta partials
+        return launch_ln_param_reduce(g.prob[0].ln_part, grid, BN, g.prob[0].ln_dgamma, g.prob[0].ln_dbeta, stream);
     return BVC_OK;
 }
 
 static int epi_class(int epi, GemmLayout layout) {
     if (layout == GEMM_TN) return epi == EPI_F32 ? 2 : -1;
+    if (epi == EPI_RESID_LN) return layout == GEMM_NT ? 4 : -1;
+    if (epi == EPI_DLN) return layout == GEMM_NN ? 5 : -1;
     switch (epi) {
         case EPI_BF16: case EPI_GELU: case EPI_RELU: return 0;
         case EPI_DGELU: case EPI_DRELU: return 3;
@@ -885,9 +1131,15 @@ int launch_gemm8(const GemmGroup& g, GemmLayout layout, int bn, hipStream_t stre
     if (total <= 0) return 1;
 #define BVC_G8(BN_, AT_, BT_, EC_) return launch_gemm8_one<256, BN_, AT_, BT_, EC_>(g, total, stream)
     if (bn == 384) {
-        if (layout != GEMM_TN) return 1;
-        return launch_gemm8_one<128, 384, true, true, 2>(g, total, stream);
+        if (layout == GEMM_TN) return ec == 2 ? launch_gemm8_one<128, 384, true, true, 2>(g, total, stream) : 1;
+        // row epilogues: one problem whose rows are exactly one tile wide, offsets of whole rows inside 32 bits
+        const GemmProblem& p = g.prob[0];
+        if (g.nprob != 1 || p.N != 384 || p.ldc != 384 || (double)p.M * 1536.0 >= 4294000000.0) return 1;
+        if (ec == 4 && layout == GEMM_NT) return launch_gemm8_one<128, 384, false, false, 4>(g, total, stream);
+        if (ec == 5 && layout == GEMM_NN) return launch_gemm8_one<128, 384, false, true, 5>(g, total, stream);
+        return 1;
     }
+    if (ec >= 4) return 1;
     if (layout == GEMM_NT) {
         if (ec == 0) { if (bn == 256) BVC_G8(256, false, false, 0); else BVC_G8(128, false, false, 0); }
         if (ec == 3) { if (bn == 256) BVC_G8(256, false, false, 3); else BVC_G8(128, false, false, 3); }

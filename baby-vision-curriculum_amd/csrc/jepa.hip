@@ -236,7 +236,7 @@ int bvc_vit_forward_px(bvc_vit_ctx* c, const void* imgs_any, const bvc_pixel_for
     }
     for (int i = 0; i < c->st.nlayers; ++i) {
         float* xo = i + 1 < c->st.nlayers ? c->st.act[i + 1].x_in : c->st.x_out;
-        TRY(layer_forward(c->w, c->st, i, L.blocks[i], c->st.act[i].x_in, xo, B, N, st));
+        TRY(layer_forward(c->w, c->st, i, L.blocks[i], c->st.act[i].x_in, xo, B, N, st, i + 1 < c->st.nlayers ? &L.blocks[i + 1] : nullptr));
     }
     TRY(launch_ln_fwd(c->st.x_out, identity_rows(), params + L.norm_w, params + L.norm_b, nullptr, c->meanf, c->rstdf, M, D, cf.eps, st, out));
     c->have_forward = true;
@@ -360,7 +360,7 @@ int bvc_predictor_forward(bvc_pred_ctx* c, const float* z, const int* idx_ctx, c
     TRY(launch_pred_assemble(c->xe, params + L.mask_token, params + L.pos, idx_pred, c->st.act[0].x_in, nsets, B, Nc, Np, Dp, st));
     for (int i = 0; i < c->st.nlayers; ++i) {
         float* xo = i + 1 < c->st.nlayers ? c->st.act[i + 1].x_in : c->st.x_out;
-        TRY(layer_forward(c->w, c->st, i, L.blocks[i], c->st.act[i].x_in, xo, S, T, st));
+        TRY(layer_forward(c->w, c->st, i, L.blocks[i], c->st.act[i].x_in, xo, S, T, st, i + 1 < c->st.nlayers ? &L.blocks[i + 1] : nullptr));
     }
     const RowMap tail{Np, T, Nc};
     TRY(launch_ln_fwd(c->st.x_out, tail, params + L.norm_w, params + L.norm_b, c->lnf, c->meanf, c->rstdf, Mo, Dp, cf.eps, st));

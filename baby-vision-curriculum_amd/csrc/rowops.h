@@ -30,6 +30,9 @@ size_t ln_bwd_workspace_floats(int M, int D);
 size_t ln_bwd_workspace_floats_upto(int Mmax, int D);
 int launch_ln_bwd(const bf16_t* dy, const float* x, RowMap rm, const float* mean, const float* rstd, const float* gamma,
                   float* dres, int accumulate, bf16_t* dres_bf, float* dgamma, float* dbeta, float* part, int M, int D, hipStream_t s);
+// dgamma[c] += sum_b part[b][0][c], dbeta[c] += sum_b part[b][1][c] over nblk partial rows of [2][D] floats (what ln_bwd and the fused
+// LayerNorm-backward epilogue of gemm8.hip leave behind)
+int launch_ln_param_reduce(const float* part, int nblk, int D, float* dgamma, float* dbeta, hipStream_t s);
 int launch_colsum_bf16(const bf16_t* X, int M, int N, int ld, float alpha, float* out, hipStream_t s);
 int launch_colsum_bf16_scaled(const bf16_t* X, int M, int N, int ld, float alpha, const float* alpha_dev, float* out, hipStream_t s);
 int launch_colsum_f32(const float* X, RowMap rm, int M, int D, float* out, hipStream_t s);

@@ -1150,6 +1150,12 @@ int launch_ln_bwd(const bf16_t* dy, const float* x, RowMap rm, const float* mean
     if (rpb == 16) { if (half) BVC_LN_BWD(16, 32); else BVC_LN_BWD(16, 64); }
     else { if (half) BVC_LN_BWD(8, 32); else BVC_LN_BWD(4, 64); }
 #undef BVC_LN_BWD
+    BVC_CHECK_HIP(hipGetLastError());
+    return launch_ln_param_reduce(part, nblk, D, dgamma, dbeta, s);
+}
+
+int launch_ln_param_reduce(const float* part, int nblk, int D, float* dgamma, float* dbeta, hipStream_t s) {
+    BVC_REQUIRE(part && dgamma && dbeta && nblk > 0 && D > 0, "ln_param_reduce: bad argument");
     hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((2 * D + 255) / 256, (nblk + 15) / 16), dim3(256), 0, s, part, nblk, D, dgamma, dbeta);
     BVC_CHECK_HIP(hipGetLastError());
     return BVC_OK;

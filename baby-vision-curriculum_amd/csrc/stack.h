@@ -57,6 +57,8 @@ struct Stack {
     // attention width: heads of hd = D / H dims run at hdp dims (hdp == hd unless hd is not 32 / 64, e.g. 24 -> 32, zero padded);
     // Da = H * hdp is the row width of qkv thirds and of ctx.  Scratch below exists only when hdp != hd.
     int hd, hdp, Da;
+    // set by a layer whose fc2 epilogue already produced the NEXT layer's first LayerNorm (ln1o / mean1 / rstd1), cleared by the consumer
+    bool ln1_ready = false;
     bf16_t *wqkv_pad = nullptr, *wo_pad = nullptr;             // bf16 [3 Da][D], [D][Da]
     float *bqkv_pad = nullptr;                                 // f32 [3 Da]
     float *gwqkv_pad = nullptr, *gbqkv_pad = nullptr, *gwo_pad = nullptr;   // f32 gradients in the padded layout
@@ -107,7 +109,12 @@ GemmProblem gemm(const bf16_t* A, size_t a_elems, int lda, const bf16_t* B, size
 int plan_dw(GemmProblem* g, int n);
 int join_side(Work& w, int parity, hipStream_t st, bvc_bucket_fn on_bucket, void* user);
 void begin_backward(Work& w);
-int layer_forward(Work& w, Stack& s, int li, const LayerOff& o, const float* x_in, float* x_out, int B, int N, hipStream_t st);
+// next: the parameters of layer li + 1 when its activations are s.act[li + 1] (its first LayerNorm may then be produced by this
+// layer's fc2 epilogue), nullptr for the last layer or when the caller reuses one set of activations
+int layer_forward(Work& w, Stack& s, int li, const LayerOff& o, const float* x_in, float* x_out, int B, int N, hipStream_t st,
+                  const LayerOff* next = nullptr);
+// Do the LayerNorms of this stack run inside the epilogues of the 384-wide products next to them (gemm8.hip, EPI_RESID_LN / EPI_DLN)?
+bool fuse_row_ln(const Stack& s, int M);
 int layer_backward(Work& w, Stack& s, int li, const LayerOff& o, const float* x_in, float* dres, float* G, int B, int N,
                    hipStream_t st, bvc_bucket_fn on_bucket, void* user);
 

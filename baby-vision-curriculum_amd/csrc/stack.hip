@@ -112,7 +112,7 @@ int alloc_work(Arena& a, Work& w, size_t MD, size_t MI, size_t delta_elems, size
     TRY(a.alloc(&w.dln, MD));
     TRY(a.alloc(&w.dctx, MD));
     TRY(a.alloc(&w.delta, delta_elems));
-    TRY(a.alloc(&w.ln_part, lnpart_elems));
+    TRY(a.alloc(&w.ln_part, std::max(lnpart_elems, kRowLnPartFloats)));      // (also the per-workgroup partial rows of the fused LayerNorm backward)
     // Measured on MI355X (B=16): running the grouped dW launch on a side stream next to the dX chain gains nothing
     // (1398 vs 1419 clips/s) - each GEMM already holds all of a CU's LDS - so it is opt-in for experiments.
     w.overlap = false;      // bvc_set_option("dw_overlap", 1), read at every begin_backward
@@ -236,13 +236,31 @@ int plan_dw(GemmProblem* g, int n) {
     return tile;
 }
 
-int layer_forward(Work& w, Stack& s, int li, const LayerOff& o, const float* x_in, float* x_out, int B, int N, hipStream_t st) {
+// A 128 x 384 tile of gemm8.hip holds complete rows of a 384-wide Linear output, so the LayerNorm that follows proj / fc2 (forward) or
+// precedes fc1 / qkv (backward: their dX products) runs in that product's epilogue instead of as an HBM pass of its own.  Measured at 256
+// clips (profiles/r05_*): decoder proj + LN ... ; below ~2 rounds of units the one-workgroup-per-CU kernel does not pay (as for every
+// gemm8 product), so small batches keep the separate passes.  bvc_set_option("row_ln", 1 / -1) forces either way; a forced gemm8 forces it too.
+bool fuse_row_ln(const Stack& s, int M) {
+    const int mode = options().row_ln;
+    if (mode < 0 || options().gemm8 < 0) return false;
+    if (!gemm_row_ln_ok(M, s.D, s.D) || s.I % 64 != 0 || (3 * s.Da) % 64 != 0) return false;
+    if ((size_t)M * std::max<size_t>(3 * (size_t)s.Da, (size_t)s.I) * 2 >= 0x80000000ull) return false;    // gemm8 addresses operands below 2 GiB
+    if (mode > 0 || options().gemm8 > 0) return true;
+    return M >= 128 * 448;
+}
+
+int layer_forward(Work& w, Stack& s, int li, const LayerOff& o, const float* x_in, float* x_out, int B, int N, hipStream_t st,
+                  const LayerOff* next) {
     LayerAct& a = s.act[li];
     const int D = s.D, I = s.I, M = B * N;
     const float* P = w.params;
     const bf16_t* W = w.wbf;
     const float eps = s.eps;
-    TRY(launch_ln_fwd(x_in, identity_rows(), P + o.ln1w, P + o.ln1b, a.ln1o, a.mean1, a.rstd1, M, D, eps, st));
+    const bool fuse = fuse_row_ln(s, M);
+    if (li == 0) s.ln1_ready = false;
+    // (the previous layer's fc2 epilogue may have left this layer's first LayerNorm behind)
+    if (!(fuse && s.ln1_ready)) TRY(launch_ln_fwd(x_in, identity_rows(), P + o.ln1w, P + o.ln1b, a.ln1o, a.mean1, a.rstd1, M, D, eps, st));
+    s.ln1_ready = false;
     const int Da = s.Da;
     const bool pad = s.hdp != s.hd;
     const bf16_t *Wqkv = W + o.wqkv, *Wo = W + o.wo;
@@ -259,20 +277,27 @@ int layer_forward(Work& w, Stack& s, int li, const LayerOff& o, const float* x_i
     }
     TRY(launch_attn_fwd(a.qkv, a.ctx, a.lse, B, N, s.H, s.hdp, st, sm_scale));
     {
-        GemmProblem p = gemm(a.ctx, (size_t)M * Da, Da, Wo, (size_t)D * Da, Da, M, D, Da, EPI_RESID, a.h, D);
+        GemmProblem p = gemm(a.ctx, (size_t)M * Da, Da, Wo, (size_t)D * Da, Da, M, D, Da, fuse ? EPI_RESID_LN : EPI_RESID, a.h, D);
         p.bias = P + o.bo; p.resid = x_in;
+        if (fuse) { p.C2 = a.ln2o; p.ln_gamma = P + o.ln2w; p.ln_beta = P + o.ln2b; p.ln_mean = a.mean2; p.ln_rstd = a.rstd2; p.ln_eps = eps; }
         TRY(launch_gemm(&p, 1, GEMM_NT, -1, st));
     }
-    TRY(launch_ln_fwd(a.h, identity_rows(), P + o.ln2w, P + o.ln2b, a.ln2o, a.mean2, a.rstd2, M, D, eps, st));
+    if (!fuse) TRY(launch_ln_fwd(a.h, identity_rows(), P + o.ln2w, P + o.ln2b, a.ln2o, a.mean2, a.rstd2, M, D, eps, st));
     {
         GemmProblem p = gemm(a.ln2o, (size_t)M * D, D, W + o.w1, (size_t)I * D, D, M, I, D, EPI_GELU, a.pre, I);
         p.bias = P + o.b1; p.C2 = a.act;
         TRY(launch_gemm(&p, 1, GEMM_NT, -1, st));
     }
     {
-        GemmProblem p = gemm(a.act, (size_t)M * I, I, W + o.w2, (size_t)D * I, I, M, D, I, EPI_RESID, x_out, D);
+        const bool fuse_next = fuse && next != nullptr && li + 1 < (int)s.act.size();
+        GemmProblem p = gemm(a.act, (size_t)M * I, I, W + o.w2, (size_t)D * I, I, M, D, I, fuse_next ? EPI_RESID_LN : EPI_RESID, x_out, D);
         p.bias = P + o.b2; p.resid = a.h;
+        if (fuse_next) {      // the next layer's first LayerNorm, out of this epilogue's complete rows
+            LayerAct& an = s.act[li + 1];
+            p.C2 = an.ln1o; p.ln_gamma = P + next->ln1w; p.ln_beta = P + next->ln1b; p.ln_mean = an.mean1; p.ln_rstd = an.rstd1; p.ln_eps = eps;
+        }
         TRY(launch_gemm(&p, 1, GEMM_NT, -1, st));
+        s.ln1_ready = fuse_next;
     }
     return BVC_OK;
 }
@@ -307,11 +332,17 @@ int layer_backward(Work& c_, Stack& s, int li, const LayerOff& o, const float* x
         p.aux = a.pre; p.ldaux = I;
         TRY(launch_gemm(&p, 1, GEMM_NN, -1, st));
     }
-    {
+    const bool fuse = fuse_row_ln(s, M);
+    if (fuse) {      // dX of fc1 with the second LayerNorm's backward in its epilogue: dres += ..., dhb = bf16(dres), dgamma / dbeta
+        GemmProblem p = gemm(dh, (size_t)M * I, I, W + o.w1, (size_t)I * D, D, M, D, I, EPI_DLN, dres, D);
+        p.C2 = dhb; p.ln_x = a.h; p.ln_mean = a.mean2; p.ln_rstd = a.rstd2; p.ln_gamma = P + o.ln2w;
+        p.ln_part = c_.ln_part; p.ln_dgamma = G + o.ln2w; p.ln_dbeta = G + o.ln2b;
+        TRY(launch_gemm(&p, 1, GEMM_NN, -1, st));
+    } else {
         GemmProblem p = gemm(dh, (size_t)M * I, I, W + o.w1, (size_t)I * D, D, M, D, I, EPI_BF16, c_.dln, D);
         TRY(launch_gemm(&p, 1, GEMM_NN, -1, st));
+        TRY(launch_ln_bwd(c_.dln, a.h, identity_rows(), a.mean2, a.rstd2, P + o.ln2w, dres, 1, dhb, G + o.ln2w, G + o.ln2b, c_.ln_part, M, D, st));
     }
-    TRY(launch_ln_bwd(c_.dln, a.h, identity_rows(), a.mean2, a.rstd2, P + o.ln2w, dres, 1, dhb, G + o.ln2w, G + o.ln2b, c_.ln_part, M, D, st));
     // attention
     const int Da = s.Da;
     const bool pad = s.hdp != s.hd;
@@ -326,7 +357,12 @@ int layer_backward(Work& c_, Stack& s, int li, const LayerOff& o, const float* x
         TRY(launch_gemm(&p, 1, GEMM_NN, -1, st));
     }
     TRY(launch_attn_bwd(a.qkv, a.ctx, c_.dctx, a.lse, c_.delta, dqkv, B, N, s.H, s.hdp, st, sm_scale));
-    {
+    if (fuse) {      // dX of qkv with the first LayerNorm's backward in its epilogue: dres becomes d/d(layer input), dyb_next its bf16 copy
+        GemmProblem p = gemm(dqkv, (size_t)M * 3 * Da, 3 * Da, Wqkv, (size_t)3 * Da * D, D, M, D, 3 * Da, EPI_DLN, dres, D);
+        p.C2 = dyb_next; p.ln_x = x_in; p.ln_mean = a.mean1; p.ln_rstd = a.rstd1; p.ln_gamma = P + o.ln1w;
+        p.ln_part = c_.ln_part; p.ln_dgamma = G + o.ln1w; p.ln_dbeta = G + o.ln1b;
+        TRY(launch_gemm(&p, 1, GEMM_NN, -1, st));
+    } else {
         GemmProblem p = gemm(dqkv, (size_t)M * 3 * Da, 3 * Da, Wqkv, (size_t)3 * Da * D, D, M, D, 3 * Da, EPI_BF16, c_.dln, D);
         TRY(launch_gemm(&p, 1, GEMM_NN, -1, st));
     }
@@ -357,7 +393,7 @@ int layer_backward(Work& c_, Stack& s, int li, const LayerOff& o, const float* x
         if (pad)
             TRY(launch_unpad_head_grads(s.gwqkv_pad, s.gbqkv_pad, s.gwo_pad, G + o.wqkv, G + o.bqkv, G + o.wo, D, s.H, s.hd, s.hdp, ws));
     }
-    TRY(launch_ln_bwd(c_.dln, x_in, identity_rows(), a.mean1, a.rstd1, P + o.ln1w, dres, 1, dyb_next, G + o.ln1w, G + o.ln1b, c_.ln_part, M, D, st));
+    if (!fuse) TRY(launch_ln_bwd(c_.dln, x_in, identity_rows(), a.mean1, a.rstd1, P + o.ln1w, dres, 1, dyb_next, G + o.ln1w, G + o.ln1b, c_.ln_part, M, D, st));
     if (c_.overlap) {
         BVC_CHECK_HIP(hipEventRecord(c_.ev_join[par], c_.side));
         c_.join_pending[par] = true;

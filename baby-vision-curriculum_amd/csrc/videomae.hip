@@ -149,12 +149,14 @@ int bvc_set_option(const char* name, int value) {
     BVC_REQUIRE(name != nullptr, "set_option: null name");
     if (!strcmp(name, "gemm8")) { BVC_REQUIRE(value >= -1 && value <= 1, "set_option: gemm8 takes -1 / 0 / 1"); options().gemm8 = value; }
     else if (!strcmp(name, "dw_overlap")) options().dw_overlap = value != 0;
+    else if (!strcmp(name, "row_ln")) { BVC_REQUIRE(value >= -1 && value <= 1, "set_option: row_ln takes -1 / 0 / 1"); options().row_ln = value; }
     else BVC_REQUIRE(false, "set_option: unknown option '%s'", name);
     return BVC_OK;
 }
 int bvc_get_option(const char* name) {
     if (name && !strcmp(name, "gemm8")) return options().gemm8;
     if (name && !strcmp(name, "dw_overlap")) return options().dw_overlap;
+    if (name && !strcmp(name, "row_ln")) return options().row_ln;
     bvc::set_error("get_option: unknown option '%s'", name ? name : "(null)");
     return BVC_ERR_INVALID;
 }
@@ -292,7 +294,7 @@ int bvc_videomae_forward_px(bvc_ctx* c, const void* pixels_any, const bvc_pixel_
     }
     for (int i = 0; i < c->enc.nlayers; ++i) {
         float* xo = i + 1 < c->enc.nlayers ? c->enc.act[i + 1].x_in : c->enc.x_out;
-        TRY(layer_forward(c->w, c->enc, i, L.enc[i], c->enc.act[i].x_in, xo, B, nvis, st));
+        TRY(layer_forward(c->w, c->enc, i, L.enc[i], c->enc.act[i].x_in, xo, B, nvis, st, i + 1 < c->enc.nlayers ? &L.enc[i + 1] : nullptr));
     }
     // encoder -> decoder glue (HF:566-582)
     TRY(launch_gather_rows_bf16(c->enc.x_out, identity_rows(), c->xe_bf, Mv, D, st));
@@ -304,7 +306,7 @@ int bvc_videomae_forward_px(bvc_ctx* c, const void* pixels_any, const bvc_pixel_
     TRY(launch_fill_masked(c->dec.act[0].x_in, params + L.mask_token, c->pos_dec, c->msk_idx, B, Lq, nvis, nmask, Dd, st));
     for (int i = 0; i < c->dec.nlayers; ++i) {
         float* xo = i + 1 < c->dec.nlayers ? c->dec.act[i + 1].x_in : c->dec.x_out;
-        TRY(layer_forward(c->w, c->dec, i, L.dec[i], c->dec.act[i].x_in, xo, B, Lq, st));
+        TRY(layer_forward(c->w, c->dec, i, L.dec[i], c->dec.act[i].x_in, xo, B, Lq, st, i + 1 < c->dec.nlayers ? &L.dec[i + 1] : nullptr));
     }
     // last nmask tokens -> LayerNorm -> head, fused with the pixel-target MSE (HF:497-501,588-664)
     const RowMap tail{nmask, Lq, nvis};

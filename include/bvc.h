@@ -41,6 +41,9 @@ const char* bvc_version(void);
  *   "gemm8"       0 (default) = the measured selection; 1 = the 256-row persistent GEMM for every product it can take,
  *                 whatever its size (runs the kernel set of the 256-clip benchmark at oracle-sized batches); -1 = never
  *   "dw_overlap"  1 = a layer's grouped weight-gradient launch runs on the context's side stream (default 0)
+ *   "row_ln"      the LayerNorms of 384-wide stacks (VideoMAE decoder, JEPA predictor) inside the epilogues of the products next to
+ *                 them (BVC_EPI_RESID_LN / BVC_EPI_DLN): 0 (default) = the measured selection, 1 = whenever the shapes allow,
+ *                 -1 = never (separate LayerNorm passes)
  * bvc_get_option returns the value, or BVC_ERR_INVALID for an unknown name. */
 int bvc_set_option(const char* name, int value);
 int bvc_get_option(const char* name);
@@ -221,7 +224,7 @@ enum { BVC_GEMM_NT = 0, BVC_GEMM_NN = 1, BVC_GEMM_TN = 2 };
 enum {
     BVC_EPI_F32 = 0, BVC_EPI_BF16 = 1, BVC_EPI_GELU = 2, BVC_EPI_RESID = 3, BVC_EPI_POS = 4, BVC_EPI_E2D = 5,
     BVC_EPI_LOSS = 6, BVC_EPI_DGELU = 7, BVC_EPI_F32_BF16 = 8, BVC_EPI_RELU = 9, BVC_EPI_DRELU = 10,
-    BVC_EPI_NCE = 11, BVC_EPI_NCE_BWD = 12
+    BVC_EPI_NCE = 11, BVC_EPI_NCE_BWD = 12, BVC_EPI_RESID_LN = 13, BVC_EPI_DLN = 14
 };
 /* BVC_EPI_GELU writes TWO bf16 outputs: C2 = gelu(v + bias) and C = gelu'(v + bias), the factor the backward product needs (the
  * forward epilogue has the erf and the exponential at hand; the backward epilogue BVC_EPI_DGELU, C = v * aux with aux = that C, is
@@ -240,6 +243,19 @@ typedef struct bvc_gemm_desc {
     const int* rowtok; const float* pos; const float* labels; float* partial;
     int rin, rout;
     float* rowsum;                  /* TN only: rowsum[m] += alpha * sum_k A(m,k)  (bias gradient of the same dY) */
+    /* BVC_EPI_RESID_LN / BVC_EPI_DLN: the LayerNorm next to a Linear whose output rows are 384 wide (VideoMAE decoder, JEPA
+     * predictor), computed in the product's epilogue on 128 x 384 tiles that hold complete rows (N == ldc == 384, one problem,
+     * tile config 12 / -1).  Replaces the separate nn.LayerNorm passes of HF:339-357 / vision_transformer.py:225-231.
+     *   RESID_LN (NT):  v = alpha AB + bias + resid -> C (f32);  C2 (bf16) = (v - mean) rstd ln_gamma + ln_beta, biased variance,
+     *                   rstd = 1 / sqrt(var + ln_eps);  ln_mean / ln_rstd [M] written.
+     *   DLN (NN):       g = alpha AB = d/d(LayerNorm output);  xhat = (ln_x - ln_mean) ln_rstd;
+     *                   C (f32, in/out) += ln_rstd (g gamma - mean(g gamma) - xhat mean(g gamma xhat));  C2 (bf16) = the new C;
+     *                   ln_dgamma += sum_m g xhat, ln_dbeta += sum_m g  (through ln_part: scratch of 256 x 2 x 384 floats). */
+    const float* ln_gamma; const float* ln_beta;
+    float* ln_mean; float* ln_rstd;
+    float ln_eps;
+    const float* ln_x;
+    float* ln_part; float* ln_dgamma; float* ln_dbeta;
 } bvc_gemm_desc;
 /* tile_cfg: -1 auto; 0 = 128x128, 1 = 128x64, 2 = 64x64 (one workgroup per tile); 6 / 7 = persistent 128x128 / 128x64,
  * 9 = persistent 128x128 with deferred stores; 10 / 11 = 256x256 / 256x128, one 512-thread workgroup per CU (gemm8.hip);

@@ -9,7 +9,7 @@ import __graft_entry__ as ge
 bvc = ge.load_package()
 L = bvc._lib
 NT, NN, TN = 0, 1, 2
-EPI = dict(F32=0, BF16=1, GELU=2, RESID=3, POS=4, E2D=5, LOSS=6, DGELU=7, F32_BF16=8)
+EPI = dict(F32=0, BF16=1, GELU=2, RESID=3, POS=4, E2D=5, LOSS=6, DGELU=7, F32_BF16=8, RESID_LN=13, DLN=14)
 
 
 def stream():
@@ -21,7 +21,8 @@ def ptr(t):
 
 
 def gemm_desc(A, B, M, N, K, epi, C, ldc=None, lda=None, ldb=None, alpha=1.0, alpha_dev=None, split_k=1, C2=None,
-              bias=None, resid=None, aux=None, rowtok=None, pos=None, labels=None, partial=None, rin=0, rout=0, rowsum=None):
+              bias=None, resid=None, aux=None, rowtok=None, pos=None, labels=None, partial=None, rin=0, rout=0, rowsum=None,
+              ln_gamma=None, ln_beta=None, ln_mean=None, ln_rstd=None, ln_eps=0.0, ln_x=None, ln_part=None, ln_dgamma=None, ln_dbeta=None):
     d = L.GemmDesc()
     d.A, d.B = A.data_ptr(), B.data_ptr()
     d.M, d.N, d.K = M, N, K
@@ -44,6 +45,10 @@ def gemm_desc(A, B, M, N, K, epi, C, ldc=None, lda=None, ldb=None, alpha=1.0, al
     d.partial = partial.data_ptr() if partial is not None else None
     d.rin, d.rout = rin, rout
     d.rowsum = rowsum.data_ptr() if rowsum is not None else None
+    for name, t in (("ln_gamma", ln_gamma), ("ln_beta", ln_beta), ("ln_mean", ln_mean), ("ln_rstd", ln_rstd), ("ln_x", ln_x),
+                    ("ln_part", ln_part), ("ln_dgamma", ln_dgamma), ("ln_dbeta", ln_dbeta)):
+        setattr(d, name, t.data_ptr() if t is not None else None)
+    d.ln_eps = ln_eps
     return d
 
 

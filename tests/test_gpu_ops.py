@@ -812,3 +812,97 @@ def test_gemm8_accumulating_weight_gradient_group(Mtok):
     # and the same tile config is refused for anything but plain f32 weight gradients
     with pytest.raises(Exception):
         G.run_gemm([G.gemm_desc(dy, G.bf16_randn(I, D, seed=3), Mtok, I, D, G.EPI["F32"], torch.zeros(Mtok, I, device=dev))], G.NT, 13)
+
+
+# --------------------------------------------------------------------------- LayerNorm inside the 384-wide products (gemm8.hip EC 4 / 5)
+ROW_LN_SHAPES = [(424, 384), (5000, 1536), (25088, 1152), (40000, 384), (66000, 1536)]     # ragged last tile, 1 / many units per workgroup
+
+
+@pytest.mark.parametrize("M,K", ROW_LN_SHAPES)
+def test_gemm8_residual_layernorm_epilogue(M, K):
+    """BVC_EPI_RESID_LN (NT, 128 x 384 tiles holding complete rows): C = A W^T + bias + resid in f32 and, from the same epilogue,
+    C2 = LayerNorm(C) in bf16 with mean / rstd - what VideoMAELayer computes as `hidden + dense(...)` followed by the next
+    `layernorm_*` (HF:339-357) and Block as `x + proj(...)` / `norm2` (vision_transformer.py:225-231).  Against fp32 torch on the
+    same bf16 operands; and C bit-identical to the plain residual epilogue of the per-tile kernel."""
+    N = 384
+    gen = torch.Generator().manual_seed(70 + K)
+    A = G.bf16_randn(M, K, seed=71)
+    W = G.bf16_randn(N, K, scale=0.05, seed=72)
+    bias = (0.1 * torch.randn(N, generator=gen)).to(dev)
+    resid = (torch.randn(M, N, generator=gen) * 1.5 + 0.3).to(dev)
+    gamma = (1 + 0.1 * torch.randn(N, generator=gen)).to(dev)
+    beta = (0.1 * torch.randn(N, generator=gen)).to(dev)
+    eps = 1e-6
+    C = torch.full((M, N), float("nan"), device=dev)
+    C2 = torch.zeros(M, N, device=dev, dtype=torch.bfloat16)
+    mean, rstd = torch.zeros(M, device=dev), torch.zeros(M, device=dev)
+    d = G.gemm_desc(A, W, M, N, K, G.EPI["RESID_LN"], C, bias=bias, resid=resid, C2=C2, ln_gamma=gamma, ln_beta=beta, ln_mean=mean,
+                    ln_rstd=rstd, ln_eps=eps)
+    assert G.bvc._ops.gemm_kernel_name(d, G.NT) == "bvc::gemm8_kernel<128, 384, false, false, 4>"
+    G.run_gemm([d], G.NT)
+    torch.cuda.synchronize()
+    ref = A.float() @ W.float().t() + bias + resid
+    assert torch.isfinite(C).all()
+    assert G.rel_err(C, ref) < 2e-6
+    assert G.rel_err(mean, ref.mean(1)) < 1e-5
+    assert G.rel_err(rstd, 1.0 / torch.sqrt(ref.var(1, unbiased=False) + eps)) < 1e-5
+    ln = torch.nn.functional.layer_norm(ref, (N,), gamma, beta, eps)
+    assert G.rel_err(C2.float(), ln) < 4e-3                      # one bf16 rounding
+    assert float((C2.float() - ln).abs().max()) < 0.05
+    # the plain residual epilogue on the per-tile kernel: same K order, same arithmetic
+    Cp = torch.zeros(M, N, device=dev)
+    G.run_gemm([G.gemm_desc(A, W, M, N, K, G.EPI["RESID"], Cp, bias=bias, resid=resid)], G.NT, tile_cfg=0)
+    torch.cuda.synchronize()
+    assert torch.equal(C, Cp)
+    # deterministic
+    Cb, C2b = torch.zeros_like(C), torch.zeros_like(C2)
+    d2 = G.gemm_desc(A, W, M, N, K, G.EPI["RESID_LN"], Cb, bias=bias, resid=resid, C2=C2b, ln_gamma=gamma, ln_beta=beta, ln_mean=mean,
+                     ln_rstd=rstd, ln_eps=eps)
+    G.run_gemm([d2], G.NT)
+    torch.cuda.synchronize()
+    assert torch.equal(C, Cb) and torch.equal(C2, C2b)
+
+
+@pytest.mark.parametrize("M,K", ROW_LN_SHAPES)
+def test_gemm8_layernorm_backward_epilogue(M, K):
+    """BVC_EPI_DLN (NN): g = dY W is d/d(LayerNorm output); the epilogue applies nn.LayerNorm's backward on the complete rows:
+    dres += rstd (g gamma - mean(g gamma) - xhat mean(g gamma xhat)), the bf16 copy, dgamma += sum g xhat, dbeta += sum g.
+    Against fp32 torch autograd of layer_norm on the same bf16 operands."""
+    N = 384
+    gen = torch.Generator().manual_seed(80 + K)
+    dY = G.bf16_randn(M, K, seed=81)
+    W = G.bf16_randn(K, N, scale=0.05, seed=82)
+    x = (torch.randn(M, N, generator=gen) * 2 + 0.5).to(dev)
+    gamma = (1 + 0.1 * torch.randn(N, generator=gen)).to(dev)
+    dres0 = torch.randn(M, N, generator=gen).to(dev)
+    eps = 1e-6
+    mean = x.mean(1).contiguous()
+    rstd = (1.0 / torch.sqrt(x.var(1, unbiased=False) + eps)).contiguous()
+    dres = dres0.clone()
+    dbf = torch.zeros(M, N, device=dev, dtype=torch.bfloat16)
+    dg0, db0 = torch.randn(N, generator=gen).to(dev), torch.randn(N, generator=gen).to(dev)     # the parameter gradients ACCUMULATE
+    dg, db = dg0.clone(), db0.clone()
+    part = torch.zeros(512 * 2 * N, device=dev)
+    d = G.gemm_desc(dY, W, M, N, K, G.EPI["DLN"], dres, C2=dbf, ln_gamma=gamma, ln_mean=mean, ln_rstd=rstd, ln_x=x, ln_part=part,
+                    ln_dgamma=dg, ln_dbeta=db)
+    assert G.bvc._ops.gemm_kernel_name(d, G.NN) == "bvc::gemm8_kernel<128, 384, false, true, 5>"
+    G.run_gemm([d], G.NN)
+    torch.cuda.synchronize()
+    g = dY.float() @ W.float()
+    xr = x.clone().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), torch.zeros(N, device=dev, requires_grad=True)
+    torch.nn.functional.layer_norm(xr, (N,), gr, br, eps).backward(g)
+    assert torch.isfinite(dres).all()
+    assert G.rel_err(dres - dres0, xr.grad) < 2e-5
+    assert G.rel_err(dres, dres0 + xr.grad) < 2e-6
+    assert G.rel_err(dbf.float(), dres) < 4e-3
+    assert G.rel_err(dg - dg0, gr.grad) < 2e-5 and G.rel_err(db - db0, br.grad) < 2e-5
+    # run to run: rows are deterministic (fixed-order reductions inside a workgroup); the parameter gradients go through the per-block
+    # partial rows and f32 atomics of ln_param_reduce like the separate LayerNorm backward's
+    dres2, dbf2 = dres0.clone(), torch.zeros_like(dbf)
+    dg2, db2 = dg0.clone(), db0.clone()
+    G.run_gemm([G.gemm_desc(dY, W, M, N, K, G.EPI["DLN"], dres2, C2=dbf2, ln_gamma=gamma, ln_mean=mean, ln_rstd=rstd, ln_x=x, ln_part=part,
+                            ln_dgamma=dg2, ln_dbeta=db2)], G.NN)
+    torch.cuda.synchronize()
+    assert torch.equal(dres, dres2) and torch.equal(dbf, dbf2)
+    assert G.rel_err(dg2, dg) < 1e-6 and G.rel_err(db2, db) < 1e-6

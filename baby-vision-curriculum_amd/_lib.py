@@ -162,6 +162,7 @@ SYMBOLS = {
     "bvc_op_adam_prepare": (c_int, [c_void_p, c_double, c_double, c_double, c_void_p, c_void_p]),
     "bvc_op_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_double, c_double, c_double, c_double, c_double,
                                  c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "bvc_op_row_ln_selected": (c_int, [c_int, c_int, c_int, c_int]),
     "bvc_op_sgd_step_segments": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                          c_int, c_void_p, c_void_p]),
     "bvc_op_adam_step_segments": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,

@@ -41,7 +41,9 @@ constexpr int kMaxGroup = 4;
 //   dw_overlap: 1 = the grouped weight-gradient launch of a layer runs on the context's side stream (no gain measured; A/B only)
 //   row_ln:     LayerNorm fused into the neighbouring 384-wide product (gemm8.hip EC 4 / 5): 0 = the measured selection, 1 = whenever
 //               the shapes allow, -1 = never (the separate ln_fwd / ln_bwd passes)
-struct Options { int gemm8 = 0; int dw_overlap = 0; int row_ln = 0; };
+//   row_stagger: 1 (default) = the workgroups of a row-epilogue launch (gemm8.hip EC 4 / 5) start spread over one unit time, so that their
+//               HBM-heavy epilogues do not all fall together; 0 = all start together (A/B)
+struct Options { int gemm8 = 0; int dw_overlap = 0; int row_ln = 0; int row_stagger = 1; };
 Options& options();
 
 // bvc_op_gemm_kernel: while `on`, the launchers write the name of the kernel instantiation they would launch (as rocprofv3

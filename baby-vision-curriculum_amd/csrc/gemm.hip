@@ -674,6 +674,7 @@ int launch_gemm(const GemmProblem* probs, int nprob, GemmLayout layout, int tile
     g.nprob = nprob;
     g.bal_units = g.bal_lb = g.bal_tiles = 0;
     g.accum = accum ? 1 : 0;
+    g.stagger = 0;
     {
         const char* e = BVC_EXP_ENV("BVC_GEMM_DEBUG");
         g.dbg = e ? atoi(e) : 0;

@@ -211,6 +211,19 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const GemmGroup g, const 
         }
         return;
     }
+    if constexpr (EC >= 4) {
+        // Row epilogues move 490 - 690 KB per unit through HBM while a unit's K loop needs only its A rows: with every workgroup
+        // starting together the epilogues of a round fall together - all CUs queue on HBM, then all CUs compute and leave it idle
+        // (measured: unit time = K loop + epilogue at the fair share of 5.5 TB/s, profiles/r05_d_*).  The workgroups of an XCD that
+        // own one unit FEWER than the busiest ones (the last round is partial) therefore start late by a graded fraction of one unit
+        // time: the launch ends no later, and the epilogues are spread over the cycle.  When all own the same number, half a unit.
+        const int cnt = x_hi - x_lo, r = cnt % nslots, nmax = (cnt + nslots - 1) / nslots;
+        int num = 0, den = 1;
+        if (r > 0 && slot_id >= r) { num = slot_id - r + 1; den = nslots - r + 1; }
+        else if (r == 0 && nmax >= 4) { num = slot_id; den = 2 * nslots; }
+        const int quanta = __builtin_amdgcn_readfirstlane((int)((long long)g.stagger * num / den));
+        for (int i = 0; i < quanta / 127; ++i) __builtin_amdgcn_s_sleep(127);
+    }
     // experiments build (BVC_GEMM_DEBUG = 1024 + (n << 12)): every other workgroup of an XCD starts n x 3.4 us late.  All workgroups
     // walk units of the same length from the same start, so their epilogues - the only phase with store / side-input traffic - hit
     // the memory system together; a start offset persists for the whole launch and puts one half's epilogues under the other half's K loops.
@@ -1091,8 +1104,14 @@ static int launch_gemm8_one(const GemmGroup& g_in, int total, hipStream_t stream
     if constexpr (EC == 2) {
         if (plan_balance(g, BM, BN, total, ncu)) grid = ncu;    // the full-length units partition over the XCDs as before; every CU gets a workgroup
     }
+    if constexpr (EC >= 4) {
+        // one unit's time in 64-cycle quanta at ~2.1 GHz: 1.45 us per 128 x 384 x 64 K tile + the epilogue's bytes at a CU's fair share of HBM
+        const double us = 1.45 * ((g.prob[0].K + 63) / 64) + (EC == 4 ? 23.0 : 32.0);
+        g.stagger = options().row_stagger && total > ncu ? (int)(us * 33.0) : 0;
+    }
     hipLaunchKernelGGL((gemm8_kernel<BM, BN, AT, BT, EC>), dim3(grid), dim3(512), lds, stream, g, total);
     BVC_CHECK_HIP(hipGetLastError());
+    (void)0;
     if constexpr (EC == 5)      // every workgroup of the grid left one row of dgamma / dbeta partials
         return launch_ln_param_reduce(g.prob[0].ln_part, grid, BN, g.prob[0].ln_dgamma, g.prob[0].ln_dbeta, stream);
     return BVC_OK;

@@ -31,6 +31,7 @@ struct GemmGroup {
     // grid has, so every unit gives up the last K tiles of its tile: the splits cover `bal_lb` K tiles each, and the remainder of
     // each of the `bal_tiles` tiles becomes a short "tail" unit; the otherwise idle workgroups take a few tails each (launch_gemm8).
     int bal_units, bal_lb, bal_tiles;
+    int stagger;                   // row epilogues (gemm8.hip EC 4 / 5): estimated time of one unit in 64-cycle sleep quanta, 0 = all workgroups start together
     int accum;                     // tile config 13: every unit ADDS into C (f32 atomics even when K is not split) - what lets an unsplit group be balanced
     GemmProblem prob[kMaxGroup];
 };

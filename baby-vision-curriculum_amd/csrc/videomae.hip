@@ -149,6 +149,7 @@ int bvc_set_option(const char* name, int value) {
     BVC_REQUIRE(name != nullptr, "set_option: null name");
     if (!strcmp(name, "gemm8")) { BVC_REQUIRE(value >= -1 && value <= 1, "set_option: gemm8 takes -1 / 0 / 1"); options().gemm8 = value; }
     else if (!strcmp(name, "dw_overlap")) options().dw_overlap = value != 0;
+    else if (!strcmp(name, "row_stagger")) options().row_stagger = value != 0;
     else if (!strcmp(name, "row_ln")) { BVC_REQUIRE(value >= -1 && value <= 1, "set_option: row_ln takes -1 / 0 / 1"); options().row_ln = value; }
     else BVC_REQUIRE(false, "set_option: unknown option '%s'", name);
     return BVC_OK;
@@ -157,6 +158,7 @@ int bvc_get_option(const char* name) {
     if (name && !strcmp(name, "gemm8")) return options().gemm8;
     if (name && !strcmp(name, "dw_overlap")) return options().dw_overlap;
     if (name && !strcmp(name, "row_ln")) return options().row_ln;
+    if (name && !strcmp(name, "row_stagger")) return options().row_stagger;
     bvc::set_error("get_option: unknown option '%s'", name ? name : "(null)");
     return BVC_ERR_INVALID;
 }
@@ -602,6 +604,13 @@ int bvc_op_adam_step(float* params, float* grads, float* exp_avg, float* exp_avg
     BVC_REQUIRE(params && grads && exp_avg && exp_avg_sq && state3 && n >= 0, "op_adam_step: bad argument");
     return launch_adam_step(params, grads, exp_avg, exp_avg_sq, (size_t)n, lr, beta1, beta2, eps, weight_decay, decoupled, maximize,
                             state3, grad_scale, found_inf, write_unscaled_grads, (bf16_t*)bf16_shadow, (hipStream_t)stream);
+}
+int bvc_op_row_ln_selected(int tokens, int width, int mlp_width, int heads) {
+    if (tokens <= 0 || width <= 0 || heads <= 0 || width % heads != 0) return 0;
+    Stack s;
+    s.D = width; s.I = mlp_width; s.H = heads; s.nlayers = 0; s.eps = 0.f; s.x_out = nullptr;
+    s.hd = width / heads; s.hdp = s.hd <= 32 ? 32 : 64; s.Da = heads * s.hdp;
+    return fuse_row_ln(s, tokens) ? 1 : 0;
 }
 int bvc_op_sgd_step_segments(float* params, float* grads, float* momentum_buf, int64_t n, const int64_t* seg_start, const int32_t* seg_group,
                              const int32_t* blk_seg, int nseg, const bvc_sgd_groups* groups, const float* grad_scale, const float* found_inf,

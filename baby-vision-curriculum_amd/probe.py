@@ -47,14 +47,14 @@ def _gemm_rows(dev, B, add):
         Bm = _rb(dev, N, K) if layout == _ops.NT else _rb(dev, K, N)
         Bm.mul_(0.02)
         kw = {}
-        out_f32 = epi in ("F32", "RESID", "POS", "E2D", "F32_BF16")
+        out_f32 = epi in ("F32", "RESID", "POS", "E2D", "F32_BF16", "RESID_LN", "DLN")
         nbytes = 2.0 * (M * K + N * K)
         Mo = M
         if epi == "E2D":
             Mo = (M // 160) * 1568
         C = torch.empty(Mo, N, device=dev, dtype=torch.float32 if out_f32 else torch.bfloat16)
         nbytes += (4.0 if out_f32 else 2.0) * M * N
-        if epi not in ("DGELU", "E2D"):
+        if epi not in ("DGELU", "E2D", "DLN"):
             kw["bias"] = torch.zeros(N, device=dev)
         if epi == "GELU":
             kw["C2"] = torch.empty_like(C)
@@ -62,9 +62,18 @@ def _gemm_rows(dev, B, add):
         if epi == "F32_BF16":
             kw["C2"] = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
             nbytes += 2.0 * M * N
-        if epi == "RESID":
+        if epi in ("RESID", "RESID_LN"):
             kw["resid"] = torch.randn(M, N, device=dev)
             nbytes += 4.0 * M * N
+        if epi == "RESID_LN":      # + the LayerNorm of the complete rows: bf16 output, mean / rstd (gemm8.hip EC 4)
+            kw.update(C2=torch.empty(M, N, device=dev, dtype=torch.bfloat16), ln_gamma=torch.ones(N, device=dev), ln_beta=torch.zeros(N, device=dev),
+                      ln_mean=torch.empty(M, device=dev), ln_rstd=torch.empty(M, device=dev), ln_eps=1e-12)
+            nbytes += 2.0 * M * N
+        if epi == "DLN":           # LayerNorm backward in the epilogue (gemm8.hip EC 5): LayerNorm input + residual gradient in, gradient + bf16 copy out
+            kw.update(C2=torch.empty(M, N, device=dev, dtype=torch.bfloat16), ln_gamma=torch.ones(N, device=dev), ln_x=torch.randn(M, N, device=dev),
+                      ln_mean=torch.zeros(M, device=dev), ln_rstd=torch.ones(M, device=dev), ln_part=torch.empty(512 * 2 * N, device=dev),
+                      ln_dgamma=torch.zeros(N, device=dev), ln_dbeta=torch.zeros(N, device=dev))
+            nbytes += (4.0 + 4.0 + 2.0) * M * N
         if epi == "DGELU":
             kw["aux"] = _rb(dev, M, N)
             nbytes += 2.0 * M * N
@@ -110,6 +119,8 @@ def _gemm_rows(dev, B, add):
         add(name, f"{label} (tile {tile}, split {split})", count, us, fl, nb)
 
     NT, NN = _ops.NT, _ops.NN
+    # the decoder's LayerNorms inside the neighbouring products' epilogues (csrc/stack.hip: fuse_row_ln) at this batch?
+    fused = bool(_lib.lib().bvc_op_row_ln_selected(Md, Dd, Id, 6))
     one("patch embed", NT, Mv, D, 1536, "POS", 1)
     one("enc qkv", NT, Mv, 3 * D, D, "BF16", 12)
     one("enc proj", NT, Mv, D, D, "RESID", 12)
@@ -117,15 +128,22 @@ def _gemm_rows(dev, B, add):
     one("enc fc2", NT, Mv, D, I, "RESID", 12)
     one("enc->dec", NT, Mv, Dd, D, "E2D", 1)
     one("dec qkv", NT, Md, 3 * Dd, Dd, "BF16", 4)
-    one("dec proj", NT, Md, Dd, Dd, "RESID", 4)
+    if fused:
+        one("dec proj + LayerNorm", NT, Md, Dd, Dd, "RESID_LN", 4)
+    else:
+        one("dec proj", NT, Md, Dd, Dd, "RESID", 4)
     one("dec fc1+GELU", NT, Md, Id, Dd, "GELU", 4)
-    one("dec fc2", NT, Md, Dd, Id, "RESID", 4)
+    if fused:      # the last layer's fc2 has no next LayerNorm of the stack to produce
+        one("dec fc2 + next LayerNorm", NT, Md, Dd, Id, "RESID_LN", 3)
+        one("dec fc2", NT, Md, Dd, Id, "RESID", 1)
+    else:
+        one("dec fc2", NT, Md, Dd, Id, "RESID", 4)
     one("head+MSE", NT, Mm, P, Dd, "LOSS", 1)
     one("head dX", NN, Mm, Dd, P, "BF16", 1)
     one("dec dX fc2", NN, Md, Id, Dd, "DGELU", 4)
-    one("dec dX fc1", NN, Md, Dd, Id, "BF16", 4)
+    one("dec dX fc1 + LayerNorm bwd" if fused else "dec dX fc1", NN, Md, Dd, Id, "DLN" if fused else "BF16", 4)
     one("dec dX proj", NN, Md, Dd, Dd, "BF16", 4)
-    one("dec dX qkv", NN, Md, Dd, 3 * Dd, "BF16", 4)
+    one("dec dX qkv + LayerNorm bwd" if fused else "dec dX qkv", NN, Md, Dd, 3 * Dd, "DLN" if fused else "BF16", 4)
     one("enc->dec dX", NN, Mv, D, Dd, "F32_BF16", 1)
     one("enc dX fc2", NN, Mv, I, D, "DGELU", 12)
     one("enc dX fc1", NN, Mv, D, I, "BF16", 12)
@@ -168,7 +186,9 @@ def _layernorm_rows(dev, B, add):
     lib = _lib.lib()
     st = _lib.current_stream_ptr
     p = lambda t: ctypes.c_void_p(t.data_ptr())
-    for label, M, Dm, count in (("enc", B * 160, 768, 24), ("dec", B * 1568, 384, 8), ("final", B * 1408, 384, 1)):
+    fused = bool(lib.bvc_op_row_ln_selected(B * 1568, 384, 1536, 6))     # then only the first layer's first LayerNorm is a pass of its own
+    for label, M, Dm, count, count_bwd in (("enc", B * 160, 768, 24, 24), ("dec", B * 1568, 384, 1 if fused else 8, 0 if fused else 8),
+                                           ("final", B * 1408, 384, 1, 1)):
         x, dres = torch.randn(M, Dm, device=dev), torch.randn(M, Dm, device=dev)
         gmm, bta = torch.ones(Dm, device=dev), torch.zeros(Dm, device=dev)
         y, dy, dresb = _rb(dev, M, Dm), _rb(dev, M, Dm), _rb(dev, M, Dm)
@@ -180,7 +200,8 @@ def _layernorm_rows(dev, B, add):
                                                           p(ws), M, Dm, st()), "layernorm_bwd")
         e = float(M) * Dm
         add("bvc::ln_fwd_kernel", f"{label} LayerNorm fwd", count, _time(fwd), 0.0, 6 * e)
-        add("bvc::ln_bwd_kernel (+ ln_param_reduce)", f"{label} LayerNorm bwd", count, _time(bwd), 0.0, 16 * e)
+        if count_bwd:
+            add("bvc::ln_bwd_kernel (+ ln_param_reduce)", f"{label} LayerNorm bwd", count_bwd, _time(bwd), 0.0, 16 * e)
 
 
 def step_kernels(batch, device):

@@ -270,6 +270,9 @@ int bvc_op_gemm_num_tiles(const bvc_gemm_desc* problem, int tile_cfg);
  * rows of a kernel-stats table (bench.py's `roofline.kernels`); and the (tile_cfg, split_k) plan the step uses for a group of
  * weight-gradient products (returns the tile config, writes split_k into the descriptors). */
 int bvc_op_gemm_kernel(const bvc_gemm_desc* problems, int count, int layout, int tile_cfg, int stages, char* name, int name_cap);
+/* 1 when the step runs the LayerNorms of a transformer stack of this shape (tokens rows, width, MLP width, heads) inside the epilogues of
+ * the neighbouring products (BVC_EPI_RESID_LN / BVC_EPI_DLN) under the current options, 0 when they are separate passes */
+int bvc_op_row_ln_selected(int tokens, int width, int mlp_width, int heads);
 int bvc_op_gemm_plan_dw(bvc_gemm_desc* problems, int count);
 
 /* softmax(QK^T/sqrt(d))V for head_dim d = 64 or 32; qkv bf16 [B*N][3*d*H]; replaces HF:181-206 / SDPA (HF:239-252) and

@@ -238,15 +238,16 @@ int plan_dw(GemmProblem* g, int n) {
 
 // A 128 x 384 tile of gemm8.hip holds complete rows of a 384-wide Linear output, so the LayerNorm that follows proj / fc2 (forward) or
 // precedes fc1 / qkv (backward: their dX products) runs in that product's epilogue instead of as an HBM pass of its own.  Measured at 256
-// clips (profiles/r05_*): decoder proj + LN ... ; below ~2 rounds of units the one-workgroup-per-CU kernel does not pay (as for every
-// gemm8 product), so small batches keep the separate passes.  bvc_set_option("row_ln", 1 / -1) forces either way; a forced gemm8 forces it too.
+// clips (profiles/r05_e_rowln_products_stagger_b256.txt): proj + LN 416 vs 330 + 173 us, fc2 + LN 693 vs 684 + 172, dX fc1 + LN bwd 866
+// vs 562 + 472, dX qkv + LN bwd 749 vs 433 + 473; whole step -0.5 % at 16 clips ... -2.2 % at 256 (r05_h_rowln_ab_batches.txt).  Below
+// 128 units (JEPA predictor at small batches) the separate passes stay.  bvc_set_option("row_ln", 1 / -1) forces either way; a forced gemm8 forces it too.
 bool fuse_row_ln(const Stack& s, int M) {
     const int mode = options().row_ln;
     if (mode < 0 || options().gemm8 < 0) return false;
     if (!gemm_row_ln_ok(M, s.D, s.D) || s.I % 64 != 0 || (3 * s.Da) % 64 != 0) return false;
     if ((size_t)M * std::max<size_t>(3 * (size_t)s.Da, (size_t)s.I) * 2 >= 0x80000000ull) return false;    // gemm8 addresses operands below 2 GiB
     if (mode > 0 || options().gemm8 > 0) return true;
-    return M >= 128 * 448;
+    return M >= 128 * 128;     // (16 clips of 1568 tokens = 196 units: -0.5 %; 32: -1.3 %; 64: -1.3 %; 128: -2.0 %; 256: -2.2 % of the step)
 }
 
 int layer_forward(Work& w, Stack& s, int li, const LayerOff& o, const float* x_in, float* x_out, int B, int N, hipStream_t st,

@@ -463,6 +463,7 @@ int gemm_pick_tile(const GemmProblem* probs, int nprob, int tile_cfg) {
     if (tile_cfg == 9) return 0;                                  // persistent 128x128 with deferred stores
     if (tile_cfg >= 10 && tile_cfg <= 12) return tile_cfg;        // gemm8.hip: 256x256 / 256x128 / 128x384
     if (tile_cfg == 14) return tile_cfg;                          // gemm_pp.hip
+    if (tile_cfg == 15 || tile_cfg == 16) return 0;               // gemm_as.hip: 128 x 128 output tiles
     if (tile_cfg >= 0) return tile_cfg;
     // Measured on MI355X (profiles/r01_b_microbench.json): a workgroup's speed is set by its L2->LDS fill
     // rate (~70 GB/s per CU), so the big tile (64 FLOP/B) wins once it alone covers the 256 CUs ~1.5x;
@@ -585,6 +586,9 @@ int launch_gemm_big_nt(const GemmProblem& p, int cfg, hipStream_t stream);   // 
 int launch_gemm_persist(const GemmGroup& g, GemmLayout layout, int cfg, hipStream_t stream, int defer);
 // gemm8.hip: 256 x bn tiles, one 512-thread workgroup per CU; returns 1 when the group is not eligible
 int launch_gemm8(const GemmGroup& g, GemmLayout layout, int bn, hipStream_t stream);
+// gemm_as.hip: A-stationary kernel for K = 384 products with bf16 outputs (tile configs 15 / 16); returns 1 when the problem is not eligible
+int launch_gemm_as(const GemmProblem& p, GemmLayout layout, bool overlap, hipStream_t stream);
+bool gemm_as_ok(const GemmProblem& p, GemmLayout layout);
 // experiments/gemm_pp.hip (experiments build only): 128 x 256 units, K loop of one wave row under the epilogue of the other;
 // built and measured in round 4 (profiles/r04_d_*): correct, bit-identical, and NOT faster - see its header
 int launch_gemm_pp(const GemmGroup& g, GemmLayout layout, hipStream_t stream);
@@ -647,9 +651,22 @@ int launch_gemm(const GemmProblem* probs, int nprob, GemmLayout layout, int tile
         if (p.epi == EPI_DLN) BVC_REQUIRE(layout == GEMM_NN && p.ln_x && p.ln_part && p.ln_dgamma && p.ln_dbeta, "launch_gemm: DLN is an NN product with the LayerNorm input, partial scratch and parameter gradients");
         tile_cfg = 12;
     }
+    // K = 384 products with a plain bf16 output (decoder / predictor qkv): the A-stationary kernel (gemm_as.hip), whose epilogue runs under
+    // the next N tile's MFMAs.  Same-process A/B against the kernels picked below (profiles/r05_l_as_ab_batches.txt, r05_i_as_ab_b256.txt):
+    // decoder qkv -6.5 % at 16 clips, -10 % at 32 ... 128, -11.5 % at 256.  Its GELU form does not win (the GELU arithmetic beside the
+    // MFMAs costs more than it hides: +13 ... +22 % overlapped, -6 ... +5 % behind the tile) and stays a tile config for A/Bs.
+    if (tile_cfg < 0 && stages < 0 && nprob == 1 && options().gemm8 >= 0 && probs[0].epi == EPI_BF16 && gemm_as_ok(probs[0], layout) &&
+        (options().gemm8 > 0 || probs[0].M >= 16384) && BVC_EXP_ENV("BVC_GEMM_NO_AS") == nullptr)
+        return launch_gemm_as(probs[0], layout, true, stream);
     if (tile_cfg < 0 && stages < 0 && !skip_g8) {
         const int g8 = pick_gemm8(probs, nprob, layout);
         if (g8 > 0) { tile_cfg = g8; auto_g8 = true; }
+    }
+    if (tile_cfg == 15 || tile_cfg == 16) {      // gemm_as.hip: A-stationary kernel for K = 384 (16 = without the overlapped epilogue, A/B only)
+        BVC_REQUIRE(nprob == 1, "launch_gemm: tile configs 15 / 16 take one problem");
+        const int rc = launch_gemm_as(probs[0], layout, tile_cfg == 15, stream);
+        BVC_REQUIRE(rc != 1, "launch_gemm: tile configs 15 / 16 (A-stationary kernel) take NT products with K = 384, N %% 128 == 0, BF16 / GELU epilogues");
+        return rc;
     }
     if ((tile_cfg >= 3 && tile_cfg <= 5) || tile_cfg == 8) {
 #ifdef BVC_EXPERIMENTS

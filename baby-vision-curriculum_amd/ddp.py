@@ -89,6 +89,7 @@ class DistributedDataParallel(nn.Module):
         self.profile_buckets = profile_buckets
         self._timed = []              # (bytes, start event, end event) of the buckets of the current backward
         self.bucket_log = []          # per finished backward: [(bytes, ms)]
+        self.exposed_log = []         # per profiled backward: ms of the exchange that lie behind the end of the backward's own kernels
         self._device = None
         if device_ids:
             self._device = torch.device("cuda", device_ids[0]) if isinstance(device_ids[0], int) else torch.device(device_ids[0])
@@ -296,6 +297,12 @@ class DistributedDataParallel(nn.Module):
         self._loose_flushed = False
         if not self._active():
             return
+        bwd_end = None
+        if self.profile_buckets and self._timed:
+            # where the backward's own kernels end on the compute stream, BEFORE the join: what of the exchange lies behind this
+            # point is communication the step waits for ("exposed")
+            bwd_end = torch.cuda.Event(enable_timing=True)
+            bwd_end.record(torch.cuda.current_stream())
         if self._native:
             self._native.wait()
         if self._comm_stream is not None:
@@ -304,6 +311,8 @@ class DistributedDataParallel(nn.Module):
         if self.profile_buckets and self._timed:
             torch.cuda.current_stream().synchronize()
             self.bucket_log.append([(nbytes, e0.elapsed_time(e1)) for nbytes, e0, e1 in self._timed])
+            last_end = self._timed[-1][2]
+            self.exposed_log.append(max(0.0, bwd_end.elapsed_time(last_end)) if bwd_end is not None else None)
             self._timed = []
 
     def _on_loose_grad(self, _param):
@@ -353,6 +362,12 @@ class DistributedDataParallel(nn.Module):
                 o += n
 
     # ---- reporting (bench.py): algorithm bandwidth and ring bus bandwidth per bucket of the logged backwards
+    def exposed_comm_report(self):
+        """Per profiled backward: milliseconds between the end of the backward's kernels on the compute stream and the end of the
+        last bucket's collective on the communication stream - the part of the gradient exchange that is NOT hidden under backward
+        (0 when the last bucket finishes first).  Measured with profile_buckets, outside any timed region."""
+        return [None if v is None else round(v, 4) for v in self.exposed_log]
+
     def bucket_report(self):
         out = []
         n = self.world_size

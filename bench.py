@@ -307,7 +307,17 @@ def main():
         comm = {"backend": ("rccl via libbvc_hip.so (bvc_allreduce_bucket / bvc_allreduce; BVC_COMM=bvc): " + native.library)
                 if xmodel.comm_backend == "bvc-rccl" else "rccl via torch.distributed (nccl), the script's process group (default)",
                 "communicators_in_step": 1,
-                "ranks": dist.get_world_size(), "bucket_cap_mb": args.bucket_mb, "buckets_last_step": rep[-1] if rep else []}
+                "ranks": dist.get_world_size(), "bucket_cap_mb": args.bucket_mb, "buckets_last_step": rep[-1] if rep else [],
+                # per rank: what of the gradient exchange is NOT hidden under backward (end of the last bucket's collective minus end of
+                # the backward's kernels, ms; rank 0's value here, max over ranks below).  Filled by the first run with more than one
+                # rank on GPUs - none has been recorded yet ("what is and is not known about scaling")
+                "exposed_comm_ms": (xmodel.exposed_comm_report() or [None])[-1]}
+        if comm["exposed_comm_ms"] is not None and world > 1:
+            t = torch.tensor([comm["exposed_comm_ms"]], device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            comm["exposed_comm_ms_max_over_ranks"] = round(float(t), 4)
+        nc = native if xmodel.comm_backend == "bvc-rccl" else None
+        comm["rccl_ranks"] = nc.world if nc is not None and hasattr(nc, "world") else dist.get_world_size()
         xmodel.profile_buckets = False
     # BASELINE configs 4 / 5 on this GPU, outside every timed region of the headline metric (tools/bench_legs.py): their own
     # metrics, units and FLOP counts; never part of `value`

@@ -906,3 +906,36 @@ def test_gemm8_layernorm_backward_epilogue(M, K):
     torch.cuda.synchronize()
     assert torch.equal(dres, dres2) and torch.equal(dbf, dbf2)
     assert G.rel_err(dg2, dg) < 1e-6 and G.rel_err(db2, db) < 1e-6
+
+
+# --------------------------------------------------------------------------- A-stationary kernel for K = 384 (gemm_as.hip)
+@pytest.mark.parametrize("tile", [15, 16])
+@pytest.mark.parametrize("epi", ["BF16", "GELU"])
+@pytest.mark.parametrize("M,N", [(424, 1152), (5000, 1536), (33000, 384), (66000, 1536), (131072, 1152)])
+def test_gemm_a_stationary_matches_the_per_tile_kernel(M, N, epi, tile):
+    """Tile configs 15 / 16: 128-row units whose A block lives in registers for the whole sweep over N, B streamed through a three-slot
+    ring, the epilogue of an N tile under the MFMAs of the next (15) or behind its own K steps (16).  Bit-identical to gemm_kernel:
+    same K order per output element, same epilogue arithmetic.  Shapes: a ragged last unit, fewer units than CUs, one unit per CU
+    and a bit (the next unit's A block arrives under the current one), several units per workgroup."""
+    K = 384
+    A = G.bf16_randn(M, K, seed=91)
+    W = G.bf16_randn(N, K, scale=0.06, seed=92)
+    bias = (0.2 * torch.randn(N, generator=torch.Generator().manual_seed(93))).to(dev)
+    outs = []
+    for t in (tile, 0):
+        C = torch.full((M, N), 7.0, device=dev, dtype=torch.bfloat16)
+        C2 = torch.full((M, N), 7.0, device=dev, dtype=torch.bfloat16) if epi == "GELU" else None
+        d = G.gemm_desc(A, W, M, N, K, G.EPI[epi], C, bias=bias, C2=C2)
+        if t == tile:
+            assert G.bvc._ops.gemm_kernel_name(d, G.NT, t) == f"bvc::gemm_as_kernel<{'true' if epi == 'GELU' else 'false'}, {'true' if tile == 15 else 'false'}>"
+        G.run_gemm([d], G.NT, tile_cfg=t)
+        torch.cuda.synchronize()
+        outs.append((C, C2))
+    assert torch.equal(outs[0][0], outs[1][0])
+    if epi == "GELU":
+        assert torch.equal(outs[0][1], outs[1][1])
+    ref = A.float() @ W.float().t() + bias
+    if epi == "BF16":
+        assert G.rel_err(outs[0][0].float(), ref) < 4e-3
+    else:
+        assert G.rel_err(outs[0][1].float(), torch.nn.functional.gelu(ref)) < 5e-3

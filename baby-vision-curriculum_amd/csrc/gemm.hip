@@ -719,6 +719,7 @@ int launch_gemm(const GemmProblem* probs, int nprob, GemmLayout layout, int tile
             int bm, bn;
             tile_dims(cfg, bm, bn);
             g.panel[i] = (p.N + bn - 1) / bn;
+            if (BVC_EXP_ENV("BVC_G8_TN_SHORT_FAST") != nullptr) g.panel[i] = -1;
         }
         g.tile_start[i] = total;
         total += tiles_for(p, cfg) * p.split_k;

@@ -61,6 +61,10 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 #ifndef BVC_G8_ST_AUX
 #define BVC_G8_ST_AUX 0
 #endif
+// the same switch for the row epilogues (EC 4 / 5), whose outputs are the bulk of their HBM traffic (A/B: profiles/r05_p_*)
+#ifndef BVC_G8_ROW_ST_AUX
+#define BVC_G8_ROW_ST_AUX 0
+#endif
 constexpr uint32_t kInvalidBase = 0x80000000u;   // beyond every operand this kernel accepts (extents < 2 GiB)
 
 struct Unit {
@@ -114,6 +118,10 @@ __device__ __forceinline__ void decode_unit(const GemmGroup& g, int uid, Unit& u
     } else if (G > 0) {
         split = lid / ntiles;
         tile_of(lid - split * ntiles, tiles_m, tiles_n, G, tm, tn);
+    } else if (G == -1) {   // K splits slowest, tiles with the SHORTER side fastest: a run of consecutive units (one XCD's share) is a compact block
+        split = lid / ntiles;
+        const int w = lid - split * ntiles;
+        if (tiles_n > tiles_m) { tm = w % tiles_m; tn = w / tiles_m; } else { tm = w / tiles_n; tn = w % tiles_n; }
     } else {   // K splits fastest, then along the shorter side (the weight-gradient walk of gemm_kernel)
         split = lid % p.split_k;
         const int tl = lid / p.split_k;
@@ -660,7 +668,7 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const GemmGroup g, const 
                 for (int j = 0; j < TN; ++j) {
                     const f32x4 bj = *reinterpret_cast<const AS3 f32x4*>(lpar + cw + 16 * j);
                     acc[i][j] = (acc[i][j] * alpha + bj) + rs[i & 1][j];
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][j]), rc, obase + (uint32_t)(i * 32 * BN * 4 + 64 * j), 0, BVC_G8_ST_AUX);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][j]), rc, obase + (uint32_t)(i * 32 * BN * 4 + 64 * j), 0, BVC_G8_ROW_ST_AUX);
                     sum += (acc[i][j][0] + acc[i][j][1]) + (acc[i][j][2] + acc[i][j][3]);
                 }
                 // statistics of the wave's 96 columns of this row: sum, and the squares about the wave's own mean (Chan's form: the four
@@ -709,7 +717,7 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const GemmGroup g, const 
                     const uint32_t a0 = pack2bf(ya[0], ya[1]), a1 = pack2bf(ya[2], ya[3]), b0 = pack2bf(yb[0], yb[1]), b1 = pack2bf(yb[2], yb[3]);
                     const auto s0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
                     const auto s1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
-                    __builtin_amdgcn_raw_buffer_store_b128(u32x4{s0[0], s1[0], s0[1], s1[1]}, rc2, o2 + 64u * jp, 0, BVC_G8_ST_AUX);
+                    __builtin_amdgcn_raw_buffer_store_b128(u32x4{s0[0], s1[0], s0[1], s1[1]}, rc2, o2 + 64u * jp, 0, BVC_G8_ROW_ST_AUX);
                 }
             }
         } else if constexpr (EC == 5) {
@@ -786,7 +794,7 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const GemmGroup g, const 
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     acc[i][j] = ((acc[i][j] - c1) - xr[b][j] * c2) * rsd[b] + dr[j];
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][j]), rd, obase + (uint32_t)(i * 32 * BN * 4 + 64 * j), 0, BVC_G8_ST_AUX);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][j]), rd, obase + (uint32_t)(i * 32 * BN * 4 + 64 * j), 0, BVC_G8_ROW_ST_AUX);
                 }
 #pragma unroll
                 for (int jp = 0; jp < TN / 2; ++jp) {
@@ -794,7 +802,7 @@ __global__ __launch_bounds__(512, 1) void gemm8_kernel(const GemmGroup g, const 
                     const uint32_t a0 = pack2bf(ya[0], ya[1]), a1 = pack2bf(ya[2], ya[3]), b0 = pack2bf(yb[0], yb[1]), b1 = pack2bf(yb[2], yb[3]);
                     const auto w0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
                     const auto w1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
-                    __builtin_amdgcn_raw_buffer_store_b128(u32x4{w0[0], w1[0], w0[1], w1[1]}, rc2, o2base + (uint32_t)(i * 32 * BN * 2 + 64 * jp), 0, BVC_G8_ST_AUX);
+                    __builtin_amdgcn_raw_buffer_store_b128(u32x4{w0[0], w1[0], w0[1], w1[1]}, rc2, o2base + (uint32_t)(i * 32 * BN * 2 + 64 * jp), 0, BVC_G8_ROW_ST_AUX);
                 }
             };
             issue(I0{});
@@ -1063,7 +1071,7 @@ static bool plan_balance(GemmGroup& g, int bm, int bn, int total, int ncu) {
     for (int i = 0; i < g.nprob; ++i) {
         const GemmProblem& p = g.prob[i];
         if (p.split_k != S || (p.K + 63) / 64 != nt || p.epi != EPI_F32) return false;
-        if (g.tile_start[i] % S != 0 || g.panel[i] <= 0) return false;
+        if (g.tile_start[i] % S != 0 || g.panel[i] == 0) return false;
     }
     const int T = total / S, I = ncu - total, q = (T + I - 1) / I;
     double e = 6.0, c = 1.0;

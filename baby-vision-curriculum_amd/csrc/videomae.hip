@@ -143,7 +143,7 @@ int pixel_src(const void* pixels, const bvc_pixel_format* fmt, int channels, Pix
 extern "C" {
 
 const char* bvc_last_error(void) { return bvc::last_error(); }
-const char* bvc_version(void) { return "gfx950;bvc-hip-r3"; }
+const char* bvc_version(void) { return "gfx950;bvc-hip-r5"; }
 
 int bvc_set_option(const char* name, int value) {
     BVC_REQUIRE(name != nullptr, "set_option: null name");

@@ -125,5 +125,65 @@ for tag, M, D, I, tile, split in (("enc", 20480, 768, 3072, 10, 2), ("dec", 1003
         mism += 0 if e <= 2e-5 else 1
     print(f"TN group {tag} M={M} tile{tile} split {split}: {n} launches, {mism} beyond 2e-5 (worst rel {worst:.1e})", flush=True)
     bad += mism
+# round 5: the row epilogues of the 128 x 384 NT / NN tiles (EC 4: residual + LayerNorm forward, EC 5: LayerNorm backward; staggered start,
+# cross-wave statistics through LDS behind ONE barrier, wave-private column accumulators) and the A-stationary kernel (gemm_as.hip: A block
+# in registers, three-slot B ring, counted waits that include the epilogue's stores, late wave group one barrier behind).  The f32 output of
+# EC 4 must equal the per-tile residual epilogue bit for bit; everything else (bf16 LayerNorm output, mean, rstd, the LayerNorm backward's
+# rows) is a fixed-order computation and must equal the FIRST launch bit for bit; dgamma / dbeta go through atomics (1e-6).
+for M, K in ((100352, 384), (100352, 1536), (50300, 1152)):
+    N = 384
+    A, W = G.bf16_randn(M, K, seed=21), G.bf16_randn(N, K, scale=0.05, seed=22)
+    bias, gamma, beta = torch.randn(N, device=dev) * 0.1, 1 + 0.1 * torch.randn(N, device=dev), 0.1 * torch.randn(N, device=dev)
+    resid = torch.randn(M, N, device=dev)
+    Cp = torch.zeros(M, N, device=dev)
+    G.run_gemm([G.gemm_desc(A, W, M, N, K, G.EPI["RESID"], Cp, bias=bias, resid=resid)], G.NT, 0)
+    first, mism = None, 0
+    for it in range(iters):
+        C, C2 = torch.zeros(M, N, device=dev), torch.zeros(M, N, device=dev, dtype=torch.bfloat16)
+        mean, rstd = torch.zeros(M, device=dev), torch.zeros(M, device=dev)
+        noise.mul_(1.0001)
+        G.run_gemm([G.gemm_desc(A, W, M, N, K, G.EPI["RESID_LN"], C, bias=bias, resid=resid, C2=C2, ln_gamma=gamma, ln_beta=beta, ln_mean=mean,
+                                ln_rstd=rstd, ln_eps=1e-6)], G.NT)
+        noise.add_(0.5)
+        if first is None:
+            first = (C2, mean, rstd)
+        ok = torch.equal(C, Cp) and torch.equal(C2, first[0]) and torch.equal(mean, first[1]) and torch.equal(rstd, first[2])
+        mism += 0 if ok else 1
+    print(f"NT RESID_LN M={M} K={K} tile12: {iters} launches, {mism} mismatches", flush=True)
+    bad += mism
+    dY, Wt = G.bf16_randn(M, K, seed=23), G.bf16_randn(K, N, scale=0.05, seed=24)
+    x = torch.randn(M, N, device=dev) * 2 + 0.5
+    mu, rs = x.mean(1).contiguous(), (1.0 / torch.sqrt(x.var(1, unbiased=False) + 1e-6)).contiguous()
+    dres0, part = torch.randn(M, N, device=dev), torch.zeros(512 * 2 * N, device=dev)
+    first, mism = None, 0
+    for it in range(iters):
+        dres, dbf = dres0.clone(), torch.zeros(M, N, device=dev, dtype=torch.bfloat16)
+        dg, db = torch.zeros(N, device=dev), torch.zeros(N, device=dev)
+        noise.mul_(1.0001)
+        G.run_gemm([G.gemm_desc(dY, Wt, M, N, K, G.EPI["DLN"], dres, C2=dbf, ln_gamma=gamma, ln_mean=mu, ln_rstd=rs, ln_x=x, ln_part=part,
+                                ln_dgamma=dg, ln_dbeta=db)], G.NN)
+        noise.add_(0.5)
+        if first is None:
+            first = (dres, dbf, dg, db)
+        ok = torch.equal(dres, first[0]) and torch.equal(dbf, first[1]) and float((dg - first[2]).norm()) <= 1e-6 * float(first[2].norm()) and \
+            float((db - first[3]).norm()) <= 1e-6 * float(first[3].norm())
+        mism += 0 if ok else 1
+    print(f"NN DLN      M={M} K={K} tile12: {iters} launches, {mism} mismatches", flush=True)
+    bad += mism
+for M, N, epi, tile in ((100352, 1152, "BF16", 15), (100352, 1536, "GELU", 15), (50300, 1536, "GELU", 16), (401408, 1152, "BF16", 15)):
+    K = 384
+    A, W, bias = G.bf16_randn(M, K, seed=31), G.bf16_randn(N, K, scale=0.05, seed=32), torch.randn(N, device=dev) * 0.1
+    R1, R2 = torch.zeros(M, N, device=dev, dtype=torch.bfloat16), torch.zeros(M, N, device=dev, dtype=torch.bfloat16)
+    G.run_gemm([G.gemm_desc(A, W, M, N, K, G.EPI[epi], R1, bias=bias, C2=R2 if epi == "GELU" else None)], G.NT, 0)
+    mism = 0
+    for it in range(iters):
+        C1, C2 = torch.zeros_like(R1), torch.zeros_like(R2)
+        noise.mul_(1.0001)
+        G.run_gemm([G.gemm_desc(A, W, M, N, K, G.EPI[epi], C1, bias=bias, C2=C2 if epi == "GELU" else None)], G.NT, tile)
+        noise.add_(0.5)
+        ok = torch.equal(C1, R1) and (epi != "GELU" or torch.equal(C2, R2))
+        mism += 0 if ok else 1
+    print(f"NT {epi:5s} M={M} N={N} K={K} tile{tile} (gemm_as): {iters} launches, {mism} mismatches", flush=True)
+    bad += mism
 print("GEMM8 RACE SCREEN", "CLEAN" if bad == 0 else f"FAILED ({bad} mismatching launches)")
 sys.exit(1 if bad else 0)

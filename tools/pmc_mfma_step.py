@@ -4,7 +4,7 @@
   MFMA busy of a kernel = SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8 XCDs)
 i.e. the share of the kernel's own GPU cycles in which a SIMD's matrix pipe is executing, averaged over the 1024 SIMDs; the clock the
 chip held is GRBM cycles / kernel time when a kernel-trace duration is available.  Dispatches are attributed to steps by the
-once-per-step `sgd_step_kernel`; the last S steps are averaged.
+once-per-step `sgd_step_kernel` / `sgd_step_seg_kernel`; the last S steps are averaged.
 
 usage: python tools/pmc_mfma_step.py <pmc_dir> <steps> <out.txt>
 """
@@ -25,7 +25,7 @@ def main():
         disp[i][r["Counter_Name"]] = float(r["Counter_Value"])
         name[i] = r["Kernel_Name"]
     ids = sorted(disp)
-    ends = [k for k, i in enumerate(ids) if "sgd_step_kernel" in name[i]]
+    ends = [k for k, i in enumerate(ids) if "sgd_step_kernel" in name[i] or "sgd_step_seg_kernel" in name[i]]
     if len(ends) < steps + 1:
         raise SystemExit(f"only {len(ends)} optimiser launches found")
     sel = ids[ends[-steps - 1] + 1:ends[-1] + 1]

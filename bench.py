@@ -38,7 +38,7 @@ def measured_traffic(batch):
 
     bench.py cannot collect TCC counters on itself; `tools/gpu_check.sh traffic` runs THIS script under
     `rocprofv3 --kernel-trace --pmc FETCH_SIZE` and again under `--pmc WRITE_SIZE` (separate passes, as the
-    microarchitecture guide prescribes) and tools/pmc_traffic.py reduces them (KiB -> bytes, FETCH_SIZE x2 on
+    microarchitecture guide prescribes) and tools/pmc/pmc_traffic.py reduces them (KiB -> bytes, FETCH_SIZE x2 on
     gfx950) into profiles/traffic_b<batch>.json, which is what is reported here, per step like `achieved`."""
     path = os.path.join(ROOT, "profiles", f"traffic_b{batch}.json")
     try:

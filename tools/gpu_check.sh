@@ -25,9 +25,9 @@ for step in "$@"; do
     # the same-process A/B tools flip per-launch environment switches that exist only in an experiments build of the library
     exp)   export BVC_EXTRA_HIPCC_FLAGS=-DBVC_EXPERIMENTS; run expbuild 400 python -c "import __graft_entry__ as g; g.build()" ;;
     noexp) unset BVC_EXTRA_HIPCC_FLAGS; run prodbuild 400 python -c "import __graft_entry__ as g; g.build()" ;;
-    g8ab)  run g8ab 500 python tools/gemm8_ab.py ;;
-    g8store) run g8store 300 python tools/g8_store_cost.py ;;
-    dwwalk) run dwwalk 300 python tools/dw_walk_ab.py ;;
+    g8ab)  run g8ab 500 python tools/ab/gemm8_ab.py ;;
+    g8store) run g8store 300 python tools/ab/g8_store_cost.py ;;
+    dwwalk) run dwwalk 300 python tools/ab/dw_walk_ab.py ;;
     # forced data-parallel path on ONE GPU (world size 1 over RCCL: every fence, stream hop and collective launch of the N-GPU job,
     # no bytes on xGMI): overhead of the wrapper per bucket size, next to the plain run
     ddpsweep) run ddp_plain 200 python bench.py --no-cpu-baseline --steps 20
@@ -63,21 +63,21 @@ PY
     bench64) run bench64 400 python bench.py --batch 64 --no-cpu-baseline --steps 15 ;;
     benchq) run benchq 300 python bench.py --no-cpu-baseline ;;
     benchddp) BVC_FORCE_DDP=1 run benchddp 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --steps 20 --warmup 3 --no-cpu-baseline ;;
-    micro) run micro 400 python tools/microbench.py ;;
+    micro) run micro 400 python tools/ab/microbench.py ;;
     racescreen) run racescreen 500 python tools/persist_race_screen.py ;;
     g8race) run g8race 600 python tools/g8_race_screen.py ;;
     probe_step) run probe_step_b${BVC_BATCH:-256} 300 python tools/step_probe.py ;;
     simclr64) run simclr64 900 python -m pytest tests/test_gpu_simclr.py -m gpu -q -x -s -p no:cacheprovider -k "64_pairs" ;;
     attntests) run attntests 400 python -m pytest tests/test_gpu_ops.py -m gpu -q -x -p no:cacheprovider -k attention ;;
     lossdbg) run lossdbg 300 python tools/debug/g8_loss_dbg.py ;;
-    dwab)  run dwab 400 python tools/dw_tile_ab.py ;;
-    dwbal) run dwbal 400 python tools/dw_balance_ab.py ;;
-    dwhead) BVC_HEAD=1 run dwhead 400 python tools/dw_balance_ab.py ;;
-    phase) run phase 500 python tools/phase_ab.py ;;
-    attnnw) run attnnw 400 python tools/attn_nw_ab.py ;;
-    gemmdbg) run gemmdbg 300 python tools/gemm_dbg.py ;;
-    ksweep) run ksweep 400 python tools/gemm_ksweep.py ;;
-    dwsweep) run dwsweep 400 python tools/dw_sweep.py ;;
+    dwab)  run dwab 400 python tools/ab/dw_tile_ab.py ;;
+    dwbal) run dwbal 400 python tools/ab/dw_balance_ab.py ;;
+    dwhead) BVC_HEAD=1 run dwhead 400 python tools/ab/dw_balance_ab.py ;;
+    phase) run phase 500 python tools/ab/phase_ab.py ;;
+    attnnw) run attnnw 400 python tools/ab/attn_nw_ab.py ;;
+    gemmdbg) run gemmdbg 300 python tools/ab/gemm_dbg.py ;;
+    ksweep) run ksweep 400 python tools/ab/gemm_ksweep.py ;;
+    dwsweep) run dwsweep 400 python tools/ab/dw_sweep.py ;;
     probe) run probe 300 python tools/gemm_probe.py ;;
     jepa) run jepa 400 python tools/bench_jepa.py ;;
     jepal) run jepal 400 python tools/bench_jepa.py --model vit_large ;;
@@ -93,12 +93,12 @@ PY
            run traffic_rd 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmct/rd -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-by-batch --no-probe --no-extra --batch ${BVC_BATCH:-256}
            run traffic_wr 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmct/wr -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-by-batch --no-probe --no-extra --batch ${BVC_BATCH:-256}
            cd $R
-           run traffic 60 python tools/pmc_traffic.py $OUT/pmct/rd $OUT/pmct/wr 3 ${BVC_BATCH:-256} $OUT/traffic_b${BVC_BATCH:-256}.json
+           run traffic 60 python tools/pmc/pmc_traffic.py $OUT/pmct/rd $OUT/pmct/wr 3 ${BVC_BATCH:-256} $OUT/traffic_b${BVC_BATCH:-256}.json
            find $OUT/pmct -name "*.csv" -size +5M -delete ;;
     mfma)  rm -rf $OUT/pmcm; cd /tmp
            run mfma_pmc 400 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES --output-format csv -d $OUT/pmcm -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-by-batch --no-probe --no-extra --batch ${BVC_BATCH:-256}
            cd $R
-           run mfma_table 60 python tools/pmc_mfma_step.py $OUT/pmcm 3 $OUT/mfma_busy_b${BVC_BATCH:-256}.txt
+           run mfma_table 60 python tools/pmc/pmc_mfma_step.py $OUT/pmcm 3 $OUT/mfma_busy_b${BVC_BATCH:-256}.txt
            find $OUT/pmcm -name "*.csv" -size +5M -delete ;;
     profdefault) rm -rf $OUT/profd; cd /tmp
            run profdefault 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/profd -- python3 $R/bench.py
@@ -116,43 +116,43 @@ PY
            run prof_simclr 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_simclr -- python3 $R/tools/bench_simclr.py --vit
            cd $R; find $OUT/prof_simclr -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/kernel_stats_simclr_vitb.csv
            find $OUT/prof_simclr -name "*kernel_trace.csv" -delete ;;
-    table) run table 60 python tools/roofline_table.py $OUT/kernel_stats.csv $OUT/traffic_b${BVC_BATCH:-256}.json 7 $OUT/roofline_table_b${BVC_BATCH:-256}.txt ;;
+    table) run table 60 python tools/pmc/roofline_table.py $OUT/kernel_stats.csv $OUT/traffic_b${BVC_BATCH:-256}.json 7 $OUT/roofline_table_b${BVC_BATCH:-256}.txt ;;
     pmc_gemm) rm -rf $OUT/pmcg; cd /tmp
-           run pmc_gemm1 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA --output-format csv -d $OUT/pmcg/a -- python3 $R/tools/gemm_only.py
-           run pmc_gemm2 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_SALU SQ_INST_CYCLES_VMEM --output-format csv -d $OUT/pmcg/b -- python3 $R/tools/gemm_only.py
+           run pmc_gemm1 300 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA --output-format csv -d $OUT/pmcg/a -- python3 $R/tools/pmc/gemm_only.py
+           run pmc_gemm2 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_SALU SQ_INST_CYCLES_VMEM --output-format csv -d $OUT/pmcg/b -- python3 $R/tools/pmc/gemm_only.py
            cd $R
-           run pmc_gemm_summary 60 python tools/pmc_summary.py $OUT/pmcg/a $OUT/pmcg/b $OUT/pmc_gemm_summary.txt ;;
+           run pmc_gemm_summary 60 python tools/pmc/pmc_summary.py $OUT/pmcg/a $OUT/pmcg/b $OUT/pmc_gemm_summary.txt ;;
     pmc_g8) rm -rf $OUT/pmcg8; cd /tmp
            for c in square8192 square8192_bn128 dec_qkv enc_fc1 square8192_128x128; do
              export BVC_G8_CASE=$c
-             run pmc_g8_${c}_a 200 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA --output-format csv -d $OUT/pmcg8/$c/a -- python3 $R/tools/g8_only.py
-             run pmc_g8_${c}_b 200 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_SALU SQ_INST_CYCLES_VMEM --output-format csv -d $OUT/pmcg8/$c/b -- python3 $R/tools/g8_only.py
-             run pmc_g8_${c}_c 200 rocprofv3 --kernel-trace --pmc SQ_INSTS_VMEM SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_VMEM SQ_INSTS_SMEM SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_SCA GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmcg8/$c/c -- python3 $R/tools/g8_only.py
-             python3 $R/tools/pmc_summary.py $OUT/pmcg8/$c/a $OUT/pmcg8/$c/b $OUT/pmc_g8_$c.txt > /dev/null
-             python3 $R/tools/pmc_summary.py $OUT/pmcg8/$c/c $OUT/pmcg8/$c/c $OUT/pmc_g8_${c}_c.txt > /dev/null
+             run pmc_g8_${c}_a 200 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA --output-format csv -d $OUT/pmcg8/$c/a -- python3 $R/tools/pmc/g8_only.py
+             run pmc_g8_${c}_b 200 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_SALU SQ_INST_CYCLES_VMEM --output-format csv -d $OUT/pmcg8/$c/b -- python3 $R/tools/pmc/g8_only.py
+             run pmc_g8_${c}_c 200 rocprofv3 --kernel-trace --pmc SQ_INSTS_VMEM SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_VMEM SQ_INSTS_SMEM SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_SCA GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmcg8/$c/c -- python3 $R/tools/pmc/g8_only.py
+             python3 $R/tools/pmc/pmc_summary.py $OUT/pmcg8/$c/a $OUT/pmcg8/$c/b $OUT/pmc_g8_$c.txt > /dev/null
+             python3 $R/tools/pmc/pmc_summary.py $OUT/pmcg8/$c/c $OUT/pmcg8/$c/c $OUT/pmc_g8_${c}_c.txt > /dev/null
              find $OUT/pmcg8/$c -name "*.csv" -size +2M -delete
            done
            unset BVC_G8_CASE; cd $R; cat $OUT/pmc_g8_*.txt ;;
     pmc_dw) rm -rf $OUT/pmcdw; cd /tmp
            for c in dec10 dec12 enc10; do
              export BVC_DW_CASE=$c
-             run pmc_dw_${c}_a 200 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA --output-format csv -d $OUT/pmcdw/$c/a -- python3 $R/tools/dw_only.py
-             run pmc_dw_${c}_c 200 rocprofv3 --kernel-trace --pmc SQ_INSTS_VMEM SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmcdw/$c/c -- python3 $R/tools/dw_only.py
-             python3 $R/tools/pmc_summary.py $OUT/pmcdw/$c/a $OUT/pmcdw/$c/c $OUT/pmc_dw_$c.txt > /dev/null
+             run pmc_dw_${c}_a 200 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA --output-format csv -d $OUT/pmcdw/$c/a -- python3 $R/tools/pmc/dw_only.py
+             run pmc_dw_${c}_c 200 rocprofv3 --kernel-trace --pmc SQ_INSTS_VMEM SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmcdw/$c/c -- python3 $R/tools/pmc/dw_only.py
+             python3 $R/tools/pmc/pmc_summary.py $OUT/pmcdw/$c/a $OUT/pmcdw/$c/c $OUT/pmc_dw_$c.txt > /dev/null
              find $OUT/pmcdw/$c -name "*.csv" -size +2M -delete
            done
            unset BVC_DW_CASE; cd $R; cat $OUT/pmc_dw_*.txt ;;
     pmc_attn) rm -rf $OUT/pmcattn; cd /tmp
-           run pmc_attn_a 200 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA --output-format csv -d $OUT/pmcattn/a -- python3 $R/tools/attn_only.py
-           run pmc_attn_b 200 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_SALU SQ_INST_CYCLES_VMEM --output-format csv -d $OUT/pmcattn/b -- python3 $R/tools/attn_only.py
-           run pmc_attn_c 200 rocprofv3 --kernel-trace --pmc SQ_INSTS_VMEM SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_VMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_SCA GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmcattn/c -- python3 $R/tools/attn_only.py
-           python3 $R/tools/pmc_summary.py $OUT/pmcattn/a $OUT/pmcattn/b $OUT/pmc_attn.txt > /dev/null
-           python3 $R/tools/pmc_summary.py $OUT/pmcattn/c $OUT/pmcattn/c $OUT/pmc_attn_c.txt > /dev/null
+           run pmc_attn_a 200 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA --output-format csv -d $OUT/pmcattn/a -- python3 $R/tools/pmc/attn_only.py
+           run pmc_attn_b 200 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_SALU SQ_INST_CYCLES_VMEM --output-format csv -d $OUT/pmcattn/b -- python3 $R/tools/pmc/attn_only.py
+           run pmc_attn_c 200 rocprofv3 --kernel-trace --pmc SQ_INSTS_VMEM SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_VMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_SCA GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmcattn/c -- python3 $R/tools/pmc/attn_only.py
+           python3 $R/tools/pmc/pmc_summary.py $OUT/pmcattn/a $OUT/pmcattn/b $OUT/pmc_attn.txt > /dev/null
+           python3 $R/tools/pmc/pmc_summary.py $OUT/pmcattn/c $OUT/pmcattn/c $OUT/pmc_attn_c.txt > /dev/null
            find $OUT/pmcattn -name "*.csv" -size +2M -delete
            cd $R; cat $OUT/pmc_attn.txt $OUT/pmc_attn_c.txt ;;
     attnab) for v in $BVC_VARIANTS; do
              if [ "$v" = "prod" ]; then unset BVC_LIB_PATH; else export BVC_LIB_PATH=$R/baby-vision-curriculum_amd/libbvc_hip_$v.so; fi
-             run attnab_$v 200 python tools/attn_ab.py
+             run attnab_$v 200 python tools/ab/attn_ab.py
            done; unset BVC_LIB_PATH ;;
     *) echo "unknown step $step" ;;
   esac

@@ -97,9 +97,12 @@ def _plans_key(param_groups):
         if not ps:
             key.append(0)
             continue
+        # (the count of parameters that HAVE a gradient is part of the key: a parameter frozen after the table was built - .grad None,
+        #  torch skips it - must drop out of its segment, or the kernel would keep stepping it on the stale contents of the flat buffer)
         key.append((len(ps), ps[0].data_ptr(), ps[-1].data_ptr(),
                     ps[0].grad.data_ptr() if ps[0].grad is not None else 0,
-                    ps[-1].grad.data_ptr() if ps[-1].grad is not None else 0))
+                    ps[-1].grad.data_ptr() if ps[-1].grad is not None else 0,
+                    sum(1 for p in ps if p.grad is not None)))
     return tuple(key)
 
 

@@ -278,3 +278,31 @@ def test_reference_param_groups_match_torch_sgd_in_two_launches():
         opt.zero_grad()
         losses.append(float(loss))
     assert scaler.get_scale() == 65536.0 and losses[-1] < losses[0], (scaler.get_scale(), losses)
+
+
+def test_fused_step_skips_a_parameter_frozen_after_the_first_step():
+    """torch.optim skips a parameter whose .grad is None.  The fused optimiser steps a flat module through a segment table built on the
+    first step; a parameter that loses its gradient LATER (frozen for a curriculum stage: requires_grad_(False), .grad = None) must
+    drop out of its segment - the flat gradient buffer still holds its last gradient."""
+    cfg = jo.TINY
+    enc, pred, _tgt = _modules(cfg, jo.make_params(jo.encoder_shapes(cfg), cfg, 21), jo.make_params(jo.predictor_shapes(cfg), cfg, 22),
+                               jo.make_params(jo.encoder_shapes(cfg), cfg, 21))
+    imgs, m_enc, m_pred = jo.synthetic_inputs(cfg, 2, 6, 8, 4)
+    x, me, mp = imgs.to(dev), [m.to(dev) for m in m_enc], [m.to(dev) for m in m_pred]
+    opt = bvc.optim.SGD([{"params": list(enc.parameters())}, {"params": list(pred.parameters())}], lr=0.1, momentum=0.9, nesterov=True)
+
+    def backward():
+        z = pred(enc(x, me), me, mp)
+        (z.float() ** 2).mean().backward()
+    backward()
+    opt.step()
+    frozen = dict(enc.named_parameters())["blocks.0.mlp.fc1.weight"]
+    other = dict(enc.named_parameters())["blocks.0.mlp.fc2.weight"]
+    opt.zero_grad()
+    backward()
+    frozen.grad = None
+    before_f, before_o = frozen.detach().clone(), other.detach().clone()
+    opt.step()
+    torch.cuda.synchronize()
+    assert torch.equal(frozen.detach(), before_f)
+    assert not torch.equal(other.detach(), before_o)

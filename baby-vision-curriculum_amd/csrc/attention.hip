@@ -901,9 +901,9 @@ __global__ __launch_bounds__(320, 1) void attn_bwd_head_kernel(const bf16_t* __r
 }
 
 // ============================================================================ host launchers
-// BVC_ATTN_PLAIN_GRID=1 switches the XCD-aware block map off (same-run A/B in tools/microbench.py; read per launch)
+// BVC_ATTN_PLAIN_GRID=1 switches the XCD-aware block map off (same-run A/B in tools/ab/microbench.py; read per launch)
 static int xcd_remap() {
-#ifdef BVC_EXPERIMENTS      // same-process A/B of the XCD-aware block map (tools/microbench.py)
+#ifdef BVC_EXPERIMENTS      // same-process A/B of the XCD-aware block map (tools/ab/microbench.py)
     return getenv("BVC_ATTN_PLAIN_GRID") == nullptr;
 #else
     return 1;

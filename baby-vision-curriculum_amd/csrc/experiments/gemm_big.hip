@@ -1,6 +1,6 @@
 // EXPERIMENT (round 1, not on the product path yet): NT GEMM with a 256x128 workgroup tile, 32-deep K steps and 128x64 wave
 // tiles.  Why: with 64x64 wave tiles every MFMA flop needs 1/32 B of LDS reads, i.e. 128 B/clk/CU at MFMA peak - exactly the LDS
-// peak - and tools/gemm_ksweep.py measures 816 TFLOP/s marginal (33 % of peak) for the 128x128 kernel.  A 128x64 wave tile
+// peak - and tools/ab/gemm_ksweep.py measures 816 TFLOP/s marginal (33 % of peak) for the 128x128 kernel.  A 128x64 wave tile
 // needs 1/42.7 B/flop (75 % of the LDS peak at MFMA peak); 32-deep K steps keep two 24 KiB stages = 48 KiB per workgroup so
 // that two workgroups still share a CU.  Reached through bvc_op_gemm(tile_cfg = 3): NT layout, one problem, EPI_BF16 (+ bias).
 #ifdef BVC_EXPERIMENTS     // compiled into the library only for tools/ (see gemm_tile.h)

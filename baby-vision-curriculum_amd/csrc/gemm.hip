@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256, LB) void gemm_kernel(const GemmGroup g) {
         // On gfx950 loads and stores retire through ONE in-order counter (vmcnt): a load issued after a store cannot be
         // waited for without waiting for that store's write acknowledgement too.  The epilogue used to alternate
         // "load side input, compute, store" per chunk and so paid one store round trip per chunk - measured as ~5 us of fixed
-        // cost per tile (tools/gemm_dbg.py: decoder fc1 340 us, 201 us with the stores dropped).  All side inputs of the tile
+        // cost per tile (tools/ab/gemm_dbg.py: decoder fc1 340 us, 201 us with the stores dropped).  All side inputs of the tile
         // (bias, residual, GELU' argument, labels, positional rows) are therefore fetched FIRST, into registers the parked
         // accumulators no longer need, and the stores follow back to back.
         f32x4 bias0 = {0.f, 0.f, 0.f, 0.f}, bias1 = {0.f, 0.f, 0.f, 0.f};
@@ -463,7 +463,7 @@ int gemm_pick_tile(const GemmProblem* probs, int nprob, int tile_cfg) {
     if (tile_cfg == 9) return 0;                                  // persistent 128x128 with deferred stores
     if (tile_cfg >= 10 && tile_cfg <= 12) return tile_cfg;        // gemm8.hip: 256x256 / 256x128 / 128x384
     if (tile_cfg == 14) return tile_cfg;                          // gemm_pp.hip
-    if (tile_cfg == 15 || tile_cfg == 16) return 0;               // gemm_as.hip: 128 x 128 output tiles
+    if (tile_cfg >= 15 && tile_cfg <= 18) return 0;               // gemm_as.hip: 128 x 128 output tiles
     if (tile_cfg >= 0) return tile_cfg;
     // Measured on MI355X (profiles/r01_b_microbench.json): a workgroup's speed is set by its L2->LDS fill
     // rate (~70 GB/s per CU), so the big tile (64 FLOP/B) wins once it alone covers the 256 CUs ~1.5x;
@@ -587,14 +587,14 @@ int launch_gemm_persist(const GemmGroup& g, GemmLayout layout, int cfg, hipStrea
 // gemm8.hip: 256 x bn tiles, one 512-thread workgroup per CU; returns 1 when the group is not eligible
 int launch_gemm8(const GemmGroup& g, GemmLayout layout, int bn, hipStream_t stream);
 // gemm_as.hip: A-stationary kernel for K = 384 products with bf16 outputs (tile configs 15 / 16); returns 1 when the problem is not eligible
-int launch_gemm_as(const GemmProblem& p, GemmLayout layout, bool overlap, hipStream_t stream);
+int launch_gemm_as(const GemmProblem& p, GemmLayout layout, int variant, hipStream_t stream);
 bool gemm_as_ok(const GemmProblem& p, GemmLayout layout);
 // experiments/gemm_pp.hip (experiments build only): 128 x 256 units, K loop of one wave row under the epilogue of the other;
 // built and measured in round 4 (profiles/r04_d_*): correct, bit-identical, and NOT faster - see its header
 int launch_gemm_pp(const GemmGroup& g, GemmLayout layout, hipStream_t stream);
 
 // Which products go to the 256-row persistent kernel (gemm8.hip) when the caller leaves the tile choice open.  Fitted to the
-// same-process A/Bs of every product of the step at 16, 64 and 256 clips (profiles/r02_e_gemm8_ab_b{16,64,256}.txt, tools/gemm8_ab.py):
+// same-process A/Bs of every product of the step at 16, 64 and 256 clips (profiles/r02_e_gemm8_ab_b{16,64,256}.txt, tools/ab/gemm8_ab.py):
 // its K loop runs ~1.2 PFLOP/s against ~0.8 for the 128 x 128 kernels, but it is ONE workgroup per CU - a launch needs about two
 // full rounds of tiles and ~45 GFLOP to amortise prologue and tail, and an epilogue is not hidden by a second resident workgroup:
 //   * 256 x 256: plain bf16-output epilogues (BF16 / GELU / RELU) and f32-output ones (residual, positional, plain) with >= 448
@@ -657,15 +657,15 @@ int launch_gemm(const GemmProblem* probs, int nprob, GemmLayout layout, int tile
     // MFMAs costs more than it hides: +13 ... +22 % overlapped, -6 ... +5 % behind the tile) and stays a tile config for A/Bs.
     if (tile_cfg < 0 && stages < 0 && nprob == 1 && options().gemm8 >= 0 && probs[0].epi == EPI_BF16 && gemm_as_ok(probs[0], layout) &&
         (options().gemm8 > 0 || probs[0].M >= 16384) && BVC_EXP_ENV("BVC_GEMM_NO_AS") == nullptr)
-        return launch_gemm_as(probs[0], layout, true, stream);
+        return launch_gemm_as(probs[0], layout, 0, stream);
     if (tile_cfg < 0 && stages < 0 && !skip_g8) {
         const int g8 = pick_gemm8(probs, nprob, layout);
         if (g8 > 0) { tile_cfg = g8; auto_g8 = true; }
     }
-    if (tile_cfg == 15 || tile_cfg == 16) {      // gemm_as.hip: A-stationary kernel for K = 384 (16 = without the overlapped epilogue, A/B only)
-        BVC_REQUIRE(nprob == 1, "launch_gemm: tile configs 15 / 16 take one problem");
-        const int rc = launch_gemm_as(probs[0], layout, tile_cfg == 15, stream);
-        BVC_REQUIRE(rc != 1, "launch_gemm: tile configs 15 / 16 (A-stationary kernel) take NT products with K = 384, N %% 128 == 0, BF16 / GELU epilogues");
+    if (tile_cfg >= 15 && tile_cfg <= 18) {      // gemm_as.hip: A-stationary kernel for K = 384 (16: epilogue behind its own tile; 17 / 18: the same two with late LDS-DMA; A/Bs)
+        BVC_REQUIRE(nprob == 1, "launch_gemm: tile configs 15 - 18 take one problem");
+        const int rc = launch_gemm_as(probs[0], layout, tile_cfg - 15, stream);
+        BVC_REQUIRE(rc != 1, "launch_gemm: tile configs 15 - 18 (A-stationary kernel) take NT products with K = 384, N %% 128 == 0, BF16 / GELU epilogues");
         return rc;
     }
     if ((tile_cfg >= 3 && tile_cfg <= 5) || tile_cfg == 8) {

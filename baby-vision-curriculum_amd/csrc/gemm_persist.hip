@@ -1,6 +1,6 @@
 // Persistent 128x128 / 128x64 GEMM for the short-K products of the step (K = 384 ... 3072, tens of tile rounds per launch).
 //
-// Why (tools/gemm_dbg.py, profiles/r01_e_gemm_decomposition_b64.txt): in gemm_kernel every tile is its own workgroup, and at
+// Why (tools/ab/gemm_dbg.py, profiles/r01_e_gemm_decomposition_b64.txt): in gemm_kernel every tile is its own workgroup, and at
 // K = 384 about half of a workgroup's life is spent outside the K loop - dispatch, argument fetch, the first LDS-DMA round
 // trip to HBM (nothing to overlap it with inside the workgroup) and the epilogue: 72 of 149 us for the decoder's qkv product
 // with the stores taken out.  Here a workgroup stays resident and walks a sequence of tiles as ONE stream of K steps: the

@@ -11,7 +11,7 @@ namespace bvc {
 
 // Experiment hooks (BVC_GEMM_DEBUG bits inside the kernels, per-launch environment switches, the 32-deep-K kernels of
 // experiments/gemm_big.hip behind tile configs 3-5 / 8) exist only in a -DBVC_EXPERIMENTS build (BVC_EXTRA_HIPCC_FLAGS=-DBVC_EXPERIMENTS,
-// used by tools/gemm_dbg.py, tools/gemm_ksweep.py and the same-process A/Bs of tools/microbench.py); the product library
+// used by tools/ab/gemm_dbg.py, tools/ab/gemm_ksweep.py and the same-process A/Bs of tools/ab/microbench.py); the product library
 // compiles them out.
 #ifdef BVC_EXPERIMENTS
 #define BVC_DBG(g, bits) ((g).dbg & (bits))
@@ -25,7 +25,7 @@ struct GemmGroup {
     int nprob;
     int tile_start[kMaxGroup + 1];
     int panel[kMaxGroup];          // column tiles per panel of the tile walk (0 = the legacy walk, A/B only); see pick_panel
-    int dbg;                       // BVC_GEMM_DEBUG experiments (tools/gemm_dbg.py): 1 = drop the bf16 stores, 2 = stagger odd slots,
+    int dbg;                       // BVC_GEMM_DEBUG experiments (tools/ab/gemm_dbg.py): 1 = drop the bf16 stores, 2 = stagger odd slots,
                                    // 8 = no B-operand refills, 16 = no MFMAs, 32 = no refills at all (results are garbage for 8/16/32)
     // Balanced weight-gradient walk of gemm8.hip (0 = off): `bal_units` full-length units (tile x K split) fill fewer workgroups than the
     // grid has, so every unit gives up the last K tiles of its tile: the splits cover `bal_lb` K tiles each, and the remainder of

@@ -151,7 +151,7 @@ GemmProblem gemm(const bf16_t* A, size_t a_elems, int lda, const bf16_t* B, size
 int plan_dw(GemmProblem* g, int n) {
     // Largest tile that still gives about one full wave of blocks (256 CUs x 2 resident) once K is split; the split is capped
     // at 12 (each split adds one f32 atomic pass over the output) and at 8 K-steps per block.  Fitted to the same-box sweep
-    // in profiles/r01_d_dw_sweep.txt (tools/dw_sweep.py): dec layer group 128x128 split 4 = 125 us vs 64x64 split 2 = 155 us.
+    // in profiles/r01_d_dw_sweep.txt (tools/ab/dw_sweep.py): dec layer group 128x128 split 4 = 125 us vs 64x64 split 2 = 155 us.
     static const int bm[3] = {128, 128, 64}, bn[3] = {128, 64, 64};
     int ksteps = 1 << 30;
     for (int i = 0; i < n; ++i) ksteps = std::min(ksteps, (g[i].K + 63) / 64);

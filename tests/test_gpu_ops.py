@@ -909,14 +909,15 @@ def test_gemm8_layernorm_backward_epilogue(M, K):
 
 
 # --------------------------------------------------------------------------- A-stationary kernel for K = 384 (gemm_as.hip)
-@pytest.mark.parametrize("tile", [15, 16])
+@pytest.mark.parametrize("tile", [15, 16, 17, 18])
 @pytest.mark.parametrize("epi", ["BF16", "GELU"])
-@pytest.mark.parametrize("M,N", [(424, 1152), (5000, 1536), (33000, 384), (66000, 1536), (131072, 1152)])
+@pytest.mark.parametrize("M,N", [(424, 1152), (5000, 1536), (33000, 128), (66000, 1536), (131072, 1152)])
 def test_gemm_a_stationary_matches_the_per_tile_kernel(M, N, epi, tile):
-    """Tile configs 15 / 16: 128-row units whose A block lives in registers for the whole sweep over N, B streamed through a three-slot
-    ring, the epilogue of an N tile under the MFMAs of the next (15) or behind its own K steps (16).  Bit-identical to gemm_kernel:
-    same K order per output element, same epilogue arithmetic.  Shapes: a ragged last unit, fewer units than CUs, one unit per CU
-    and a bit (the next unit's A block arrives under the current one), several units per workgroup."""
+    """Tile configs 15 - 18: 128-row units whose A block lives in registers for the whole sweep over N; A and B tiles stream through one
+    ring of eight slots, six steps ahead; the epilogue of an N tile during the K steps of the next (15, 17) or behind its own last K
+    step (16, 18); LDS-DMA issued in the read segment (15, 16) or behind the MFMAs (17, 18).  Bit-identical to gemm_kernel: same K order
+    per output element, same epilogue arithmetic.  Shapes: a ragged last unit, fewer units than CUs, ONE N tile per unit (the stream is
+    mostly A steps), one unit per CU and a bit, several units per workgroup."""
     K = 384
     A = G.bf16_randn(M, K, seed=91)
     W = G.bf16_randn(N, K, scale=0.06, seed=92)
@@ -927,7 +928,8 @@ def test_gemm_a_stationary_matches_the_per_tile_kernel(M, N, epi, tile):
         C2 = torch.full((M, N), 7.0, device=dev, dtype=torch.bfloat16) if epi == "GELU" else None
         d = G.gemm_desc(A, W, M, N, K, G.EPI[epi], C, bias=bias, C2=C2)
         if t == tile:
-            assert G.bvc._ops.gemm_kernel_name(d, G.NT, t) == f"bvc::gemm_as_kernel<{'true' if epi == 'GELU' else 'false'}, {'true' if tile == 15 else 'false'}>"
+            want = f"bvc::gemm_as_kernel<{'true' if epi == 'GELU' else 'false'}, {'true' if tile in (15, 17) else 'false'}, {'true' if tile >= 17 else 'false'}>"
+            assert G.bvc._ops.gemm_kernel_name(d, G.NT, t) == want
         G.run_gemm([d], G.NT, tile_cfg=t)
         torch.cuda.synchronize()
         outs.append((C, C2))

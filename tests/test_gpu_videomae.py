@@ -201,7 +201,7 @@ def test_base_b64_matches_transformers_fixture_on_the_kernels_the_launcher_picks
     _log("[base_b64_s0] kernels the launcher picks at 64 clips: " + "; ".join(f"{k} -> {v}" for k, v in sorted(by_product.items())))
     must = ["enc fc1+GELU", "dec fc1+GELU", "dec fc2", "dec dX fc2", "dec dX fc1", "dec dX qkv", "enc dX fc1", "enc dX fc2",
             "head+MSE", "head dX", "head dW"]
-    assert by_product["dec qkv"] == "bvc::gemm_as_kernel<false, true>"      # K = 384, plain bf16 output: the A-stationary kernel (gemm_as.hip)
+    assert by_product["dec qkv"] == "bvc::gemm_as_kernel<false, true, false>"      # K = 384, plain bf16 output: the A-stationary kernel (gemm_as.hip)
     for name in must:      # (a product whose epilogue also carries a LayerNorm is listed as "<product> + ... LayerNorm ...")
         hits = [k for k in by_product if k == name or k.startswith(name + " +")]
         assert hits and all(by_product[k].startswith("bvc::gemm8_kernel<") for k in hits), (name, hits, [by_product[k] for k in hits])

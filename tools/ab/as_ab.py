@@ -1,5 +1,5 @@
-"""Same-process A/B of the A-stationary kernel (gemm_as.hip, tile configs 15 / 16) against what the launcher picks today for the K = 384
-products of the VideoMAE decoder.  Usage: python tools/ab/as_ab.py [clips] [rounds]"""
+"""Same-process A/B of the A-stationary kernel (gemm_as.hip, tile configs 15 - 18) against the 256 x 256 persistent kernel (tile config 10) on the
+K = 384 products of the VideoMAE decoder.  Usage: python tools/ab/as_ab.py [clips] [rounds]"""
 import os
 import sys
 
@@ -26,7 +26,7 @@ def ev_time(fn, n=3):
 
 
 print(f"{B} clips: M = {M}, K = {K}; us per launch, median [min .. max] over {ROUNDS} interleaved rounds (A and A' = the same launch twice)")
-print(f"{'product':16s} {'A: auto':>24s} {'A-prime: auto':>24s} {'B: tile 15 (overlap)':>24s} {'C: tile 16 (no overlap)':>24s} {'B / A':>7s} {'C / A':>7s}   auto kernel")
+print(f"{'product':16s} {'A: gemm8 (tile 10)':>24s} {'A-prime':>24s} {'15: ovl, early DMA':>24s} {'16: no ovl, early':>24s} {'17: ovl, late DMA':>24s} {'18: no ovl, late':>24s}  15/A  16/A  17/A  18/A")
 for name, N, epi in (("dec qkv", 1152, "BF16"), ("dec fc1+GELU", 1536, "GELU")):
     A = G.bf16_randn(M, K, seed=1)
     W = G.bf16_randn(N, K, scale=0.05, seed=2)
@@ -35,18 +35,19 @@ for name, N, epi in (("dec qkv", 1152, "BF16"), ("dec fc1+GELU", 1536, "GELU")):
     C2 = torch.empty(M, N, device=dev, dtype=torch.bfloat16) if epi == "GELU" else None
     d = G.gemm_desc(A, W, M, N, K, G.EPI[epi], C, bias=bias, C2=C2)
     kname = G.bvc._ops.gemm_kernel_name(d, G.NT)
-    fns = [lambda: G.run_gemm([d], G.NT), lambda: G.run_gemm([d], G.NT), lambda: G.run_gemm([d], G.NT, tile_cfg=15), lambda: G.run_gemm([d], G.NT, tile_cfg=16)]
+    fns = [lambda: G.run_gemm([d], G.NT, tile_cfg=10), lambda: G.run_gemm([d], G.NT, tile_cfg=10), lambda: G.run_gemm([d], G.NT, tile_cfg=15),
+           lambda: G.run_gemm([d], G.NT, tile_cfg=16), lambda: G.run_gemm([d], G.NT, tile_cfg=17), lambda: G.run_gemm([d], G.NT, tile_cfg=18)]
     for f in fns:
         ev_time(f, 2)
     t = [[] for _ in fns]
     for r in range(ROUNDS):
-        for i in (0, 2, 3, 1, 1, 3, 2, 0):
+        for i in (0, 2, 3, 4, 5, 1, 1, 5, 4, 3, 2, 0):
             t[i].append(ev_time(fns[i]))
 
     def fmt(a):
         a = np.array(a)
         return f"{np.median(a):8.1f} [{a.min():6.1f} ..{a.max():7.1f}]"
     m = [np.median(x) for x in t]
-    print(f"{name:16s} {fmt(t[0]):>24s} {fmt(t[1]):>24s} {fmt(t[2]):>24s} {fmt(t[3]):>24s} {m[2] / m[0]:7.3f} {m[3] / m[0]:7.3f}   {kname}", flush=True)
+    print(f"{name:16s} " + " ".join(f"{fmt(x):>24s}" for x in t) + "  " + " ".join(f"{m[i] / m[0]:5.3f}" for i in (2, 3, 4, 5)), flush=True)
     del A, W, C, C2
     torch.cuda.empty_cache()

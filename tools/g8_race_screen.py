@@ -170,7 +170,7 @@ for M, K in ((100352, 384), (100352, 1536), (50300, 1152)):
         mism += 0 if ok else 1
     print(f"NN DLN      M={M} K={K} tile12: {iters} launches, {mism} mismatches", flush=True)
     bad += mism
-for M, N, epi, tile in ((100352, 1152, "BF16", 15), (100352, 1536, "GELU", 15), (50300, 1536, "GELU", 16), (401408, 1152, "BF16", 15)):
+for M, N, epi, tile in ((100352, 1152, "BF16", 15), (100352, 1536, "GELU", 15), (50300, 1536, "GELU", 16), (401408, 1152, "BF16", 15), (100352, 1152, "BF16", 17), (66000, 128, "GELU", 18)):
     K = 384
     A, W, bias = G.bf16_randn(M, K, seed=31), G.bf16_randn(N, K, scale=0.05, seed=32), torch.randn(N, device=dev) * 0.1
     R1, R2 = torch.zeros(M, N, device=dev, dtype=torch.bfloat16), torch.zeros(M, N, device=dev, dtype=torch.bfloat16)

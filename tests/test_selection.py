@@ -112,3 +112,34 @@ def test_options(L):
     with pytest.raises(L.BvcError):
         L.set_option("no_such_option", 1)
     assert L.lib().bvc_get_option(b"no_such_option") < 0
+
+
+def test_a_stationary_and_row_layernorm_selection(L):
+    # round 5: K = 384 bf16 products (decoder qkv) move to the A-stationary kernel once gemm8 would have been chosen or M >= 16384 ...
+    Md = 256 * 1568
+    assert _name(L, [_desc(L, Md, 1152, 384, BF16, NT)], NT) == "bvc::gemm_as_kernel<false, true, false>"
+    assert _name(L, [_desc(L, 64 * 1568, 1152, 384, BF16, NT)], NT) == "bvc::gemm_as_kernel<false, true, false>"
+    assert "gemm_as" not in _name(L, [_desc(L, 2 * 1568, 1152, 384, BF16, NT)], NT)
+    # ... but not with the GELU epilogue (measured slower: profiles/r05_n_*), not for K != 384, not for N beyond 1536
+    gelu = _desc(L, Md, 1536, 384, GELU, NT)
+    gelu.C2 = 12288                                             # the activation output next to the pre-activation
+    assert _name(L, [gelu], NT) == "bvc::gemm8_kernel<256, 256, false, false, 0>"
+    assert "gemm_as" not in _name(L, [_desc(L, 256 * 160, 2304, 768, BF16, NT)], NT)
+    assert "gemm_as" not in _name(L, [_desc(L, Md, 1664, 384, BF16, NT)], NT)
+    assert _name(L, [gelu], NT, tile=15) == "bvc::gemm_as_kernel<true, true, false>"                                 # asked for explicitly
+    with pytest.raises(L.BvcError):
+        _name(L, [_desc(L, Md, 1152, 768, BF16, NT)], NT, tile=15)
+    L.set_option("gemm8", -1)
+    assert "gemm_as" not in _name(L, [_desc(L, Md, 1152, 384, BF16, NT)], NT)
+    L.set_option("gemm8", 0)
+    # LayerNorm fused into the 384-wide products: a stack-level choice (bvc_op_row_ln_selected mirrors stack.hip's fuse_row_ln)
+    sel = L.lib().bvc_op_row_ln_selected
+    assert sel(256 * 1568, 384, 1536, 6) == 1 and sel(64 * 1568, 384, 1536, 6) == 1 and sel(16 * 1568, 384, 1536, 6) == 1
+    assert sel(8 * 1568, 384, 1536, 6) == 0                     # below 128 row tiles of 128: the separate kernels win
+    assert sel(256 * 160, 768, 3072, 12) == 0                   # a 768-wide row does not fit one tile
+    assert sel(256 * 100, 384, 1536, 12) == 1                   # JEPA ViT-B predictor (head_dim 32) qualifies by width alone
+    old = L.set_option("row_ln", -1)
+    assert sel(256 * 1568, 384, 1536, 6) == 0
+    L.set_option("row_ln", 1)
+    assert sel(2 * 1568, 384, 1536, 6) == 1                     # forced: whatever the size
+    L.set_option("row_ln", old)

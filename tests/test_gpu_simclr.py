@@ -141,6 +141,78 @@ def test_simclr_step_like_the_reference_loop():
         assert G.rel_err(v.cpu(), r) < 5e-2, k
 
 
+def test_simclr_loop_teacher_forced_every_step_at_forward_tolerance():
+    """The same five-step loop (pretrain_simclr.py:320-329), but the arithmetic of EVERY step is checked, not only the first: before each
+    step the HIP side is set to the oracle trajectory's parameters, so step k compares the two losses at the same point (1e-3 relative, the
+    north_star bar, while the loss falls tenfold) and the optimiser update taken from it (relative L2 of the parameter change) -
+    against the same step with every GEMM operand of the head rounded to bf16 on the CPU (so.head_forward_bf16_operands: 2e-2, operand
+    rounding through a 1 / T = 10 softmax) and against the f32 oracle with the allowance the flipped ReLU gates explain, as in
+    test_projection_head_forward_backward.  VERDICT round 4, weak 3: the free-running loop above checks the plumbing, this one the
+    arithmetic."""
+    from functools import partial
+    B, p = 16, 128
+    torch.manual_seed(3)
+    trunk = torch.nn.Linear(3 * 8 * 8, p)
+    ref_trunk = torch.nn.Linear(3 * 8 * 8, p)
+    ref_trunk.load_state_dict(trunk.state_dict())
+    model = torch.nn.Sequential()
+    model.trunk, model.fc = trunk.to(dev), None
+    model = bvc.simclr._adapt_model_simclr(model, p, p).to(dev)
+    hp = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in model.fc.state_dict().items()}
+    criterion = partial(bvc.simclr.info_nce_loss, 0.1, bvc.simclr.make_masks(B, dev))
+    lr = 0.05
+    opt = torch.optim.SGD(list(model.trunk.parameters()) + list(model.fc.parameters()), lr=lr)
+    ref_opt = torch.optim.SGD(list(ref_trunk.parameters()) + list(hp.values()), lr=lr)
+    ref_criterion = partial(so.info_nce_loss, 0.1, so.make_masks(B))
+    inputs = torch.randn(B, 2, 3, 8, 8)
+    x_dev, x_cpu = inputs.to(dev), inputs.view(B * 2, -1)
+    r16 = lambda t: t.to(torch.bfloat16).float()   # noqa: E731
+    ref_losses, worst_loss, worst16, worst32 = [], 0.0, 0.0, 0.0
+    for it in range(5):
+        # both sides start the step at the oracle's parameters
+        with torch.no_grad():
+            for k, v in model.fc.state_dict().items():
+                v.copy_(hp[k].detach())
+            for (k, v), (_k, r) in zip(model.trunk.state_dict().items(), ref_trunk.state_dict().items()):
+                v.copy_(r)
+        before = {k: v.detach().clone() for k, v in hp.items()}
+        before_t = {k: v.detach().clone() for k, v in ref_trunk.state_dict().items()}
+        # the same step on bf16 GEMM operands in the head (CPU): its gradients at this point
+        bt = torch.nn.Linear(3 * 8 * 8, p)
+        bt.load_state_dict(ref_trunk.state_dict())
+        bh = {k: v.detach().clone().requires_grad_(True) for k, v in hp.items()}
+        feats = bt(x_cpu)
+        ref_criterion(so.head_forward_bf16_operands(feats, bh["0.weight"], bh["0.bias"], bh["2.weight"], bh["2.bias"])).backward()
+        pre32 = torch.nn.functional.linear(feats.detach(), before["0.weight"], before["0.bias"])
+        pre16 = torch.nn.functional.linear(r16(feats.detach()), r16(before["0.weight"]), before["0.bias"])
+        flipped = float(((pre32 > 0) != (pre16 > 0)).float().mean())
+        opt.zero_grad()
+        loss = bvc.AllReduce.apply(criterion(model.fc(model.trunk(x_dev.view(B * 2, -1)))))
+        loss.backward()
+        opt.step()
+        ref_opt.zero_grad()
+        ref_pred = so.head_forward(ref_trunk(x_cpu), hp["0.weight"], hp["0.bias"], hp["2.weight"], hp["2.bias"])
+        ref_loss = ref_criterion(ref_pred)
+        ref_loss.backward()
+        ref_opt.step()
+        ref_losses.append(float(ref_loss))
+        rel = abs(float(loss) - float(ref_loss)) / abs(float(ref_loss))
+        worst_loss = max(worst_loss, rel)
+        assert rel < 1e-3, (it, float(loss), float(ref_loss))
+        bar32 = max(3e-2, 4.0 * flipped ** 0.5)        # 32 x 128 units: four flipped gates are 1e-3 of them and ~0.1 of this gradient
+        pairs = [(k, v.cpu() - before[k], hp[k].detach() - before[k], -lr * bh[k].grad) for k, v in model.fc.state_dict().items()]
+        pairs += [("trunk." + k, v.cpu() - before_t[k], r - before_t[k], -lr * dict(bt.named_parameters())[k].grad)
+                  for (k, v), (_k, r) in zip(model.trunk.state_dict().items(), ref_trunk.state_dict().items())]
+        for k, got, want32, want16 in pairs:
+            e16, e32 = G.rel_err(got, want16), G.rel_err(got, want32)
+            worst16, worst32 = max(worst16, e16), max(worst32, e32)
+            assert e16 < 2e-2, (it, k, e16)
+            assert e32 < bar32, (it, k, e32, flipped)
+    assert ref_losses[-1] < 0.5 * ref_losses[0]                       # the trajectory did move: the later steps are different problems
+    G.log_parity(f"[simclr reference loop, teacher-forced, 5 steps] loss {ref_losses[0]:.2f} -> {ref_losses[-1]:.2f}; worst loss rel "
+                 f"{worst_loss:.2e} (bar 1e-3), worst update rel L2 vs bf16-operand step {worst16:.2e} (bar 2e-2), vs f32 step {worst32:.2e}")
+
+
 def test_simclr_vit_composition_matches_oracle():
     """BASELINE config 5 composition (the reference's video ViT with one frame as trunk + token mean + SimCLR head +
     info_nce_loss): loss within 1e-3 of the oracle composition, trunk / head gradients at bf16-operand tolerance."""

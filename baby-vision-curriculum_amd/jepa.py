@@ -421,6 +421,32 @@ def select_targets(h, masks_pred, eps=1e-5):
     return out
 
 
+_TARGET_STREAMS = {}
+
+
+def forward_target_async(target_encoder, imgs, masks_pred, eps=1e-5):
+    """forward_target of pretrain_jepa.py:384-392 (target encoder under no_grad, F.layer_norm, the prediction masks' rows), enqueued on a
+    second HIP stream so that it runs BESIDE the context encoder and the predictor: nothing consumes the targets before the loss, and at the
+    reference's 16 samples per GPU neither branch fills 256 CUs alone (ViT-B step -9 %, ViT-L -5 %, profiles/r05_z_jepa_overlap_*.txt).
+    Same kernels, same results.  Returns join(): call it where the targets are needed - it makes the current stream wait for the side
+    stream and returns h.  The side stream first waits for the current one (the EMA update of the last step wrote these parameters there)."""
+    dev = imgs.device
+    main = torch.cuda.current_stream(dev)
+    side = _TARGET_STREAMS.get(dev.index)
+    if side is None:
+        side = _TARGET_STREAMS[dev.index] = torch.cuda.Stream(dev)
+    side.wait_stream(main)
+    with torch.cuda.stream(side), torch.no_grad():
+        h = select_targets(target_encoder(imgs), masks_pred, eps)
+
+    def join():
+        cur = torch.cuda.current_stream(dev)
+        cur.wait_stream(side)
+        h.record_stream(cur)
+        return h
+    return join
+
+
 class _SmoothL1(torch.autograd.Function):
     @staticmethod
     def forward(ctx, z, h):

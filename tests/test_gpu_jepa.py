@@ -181,6 +181,53 @@ def test_ema_update_and_training_loop():
     assert all(l == l for l in losses) and losses[-1] < losses[0]
 
 
+def test_target_forward_on_a_second_stream_is_the_same_loop_bit_for_bit():
+    """bvc.jepa.forward_target_async (forward_target of pretrain_jepa.py:384-392 enqueued on a second stream, joined at the loss): five
+    steps with EMA feedback against the sequential loop on identically initialised modules - every loss and every final parameter of
+    the encoder, the predictor and the target encoder bit-equal, i.e. the two streams are ordered where the data says they must be
+    (EMA -> next target forward, target forward -> loss -> EMA)."""
+    cfg = jo.TINY
+    enc_p = jo.make_params(jo.encoder_shapes(cfg), cfg, 16)
+    pred_p = jo.make_params(jo.predictor_shapes(cfg), cfg, 17)
+    imgs, m_enc, m_pred = jo.synthetic_inputs(cfg, 4, 6, 8, 4)
+    x, me, mp = imgs.to(dev), [m.to(dev) for m in m_enc], [m.to(dev) for m in m_pred]
+
+    def run(overlap):
+        enc, pred, tgt = _modules(cfg, enc_p, pred_p, enc_p)
+        opt = bvc.optim.SGD([{"params": [p for p in enc.parameters() if p.requires_grad]},
+                             {"params": [p for p in pred.parameters() if p.requires_grad]}], lr=0.05, momentum=0.9, nesterov=True)
+        scaler = bvc.amp.GradScaler("cuda")
+        losses = []
+        for _ in range(5):
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                if overlap:
+                    join = bvc.jepa.forward_target_async(tgt, x, mp)
+                    z = pred(enc(x, me), me, mp)
+                    h = join()
+                else:
+                    with torch.no_grad():
+                        h = bvc.jepa.select_targets(tgt(x), mp)
+                    z = pred(enc(x, me), me, mp)
+                loss = bvc.jepa.smooth_l1_loss(z, h)
+            scaler.scale(loss).backward()
+            scaler.step(opt)
+            scaler.update()
+            opt.zero_grad()
+            bvc.jepa.ema_update(enc, tgt, 0.9)
+            losses.append(loss.detach().clone())
+        torch.cuda.synchronize()
+        return losses, [{k: v.detach().clone() for k, v in m.state_dict().items()} for m in (enc, pred, tgt)]
+
+    la, sa = run(False)
+    lb, sb = run(True)
+    for a, b in zip(la, lb):
+        assert torch.equal(a, b), (float(a), float(b))
+    for da, db in zip(sa, sb):
+        for k in da:
+            assert torch.equal(da[k], db[k]), k
+    assert float(la[-1]) < float(la[0])
+
+
 def test_uint8_frames_equal_normalised_f32_bitwise():
     from oracle import jepa_oracle as jo
     cfg = jo.TINY

@@ -25,7 +25,7 @@ def _timed(step, warmup, steps):
     return (time.perf_counter() - t0) / steps, float(loss.detach())
 
 
-def jepa_leg(bvc, dev, model="vit_large", batch=16, nctx=100, npred=25, warmup=3, steps=10):
+def jepa_leg(bvc, dev, model="vit_large", batch=16, nctx=100, npred=25, warmup=6, steps=10, overlap_target=True):
     torch.manual_seed(0)
     enc, pred = bvc.jepa.get_model(dev, patch_size=16, tubelet_size=1, num_frames=2, model_name=model, image_size=224)
     tgt = copy.deepcopy(enc).to(dev)
@@ -45,9 +45,16 @@ def jepa_leg(bvc, dev, model="vit_large", batch=16, nctx=100, npred=25, warmup=3
 
     def step():
         with torch.autocast("cuda", dtype=torch.bfloat16):
-            with torch.no_grad():
-                h = bvc.jepa.select_targets(tgt(imgs), mp)
-            z = pred(enc(imgs, me), me, mp)
+            if not overlap_target:
+                with torch.no_grad():
+                    h = bvc.jepa.select_targets(tgt(imgs), mp)
+                z = pred(enc(imgs, me), me, mp)
+            else:
+                # the target encoder's forward has no consumer before the loss: on a second stream it runs beside the context encoder
+                # and the predictor (bvc.jepa.forward_target_async: same kernels, same arithmetic)
+                join = bvc.jepa.forward_target_async(tgt, imgs, mp)
+                z = pred(enc(imgs, me), me, mp)
+                h = join()
             loss = bvc.AllReduce.apply(bvc.jepa.smooth_l1_loss(z, h))
         scaler.scale(loss).backward()
         scaler.step(opt)
@@ -59,7 +66,7 @@ def jepa_leg(bvc, dev, model="vit_large", batch=16, nctx=100, npred=25, warmup=3
     dt, loss = _timed(step, warmup, steps)
     gf = JEPA_GFLOP.get(model, 0.0)
     return {"workload": f"I-JEPA {model}/16, 2x224^2 inputs, {B} samples/GPU, N_ctx {nctx}, N_pred {npred} x 4, full step (target + context "
-                        "encoders, predictor, smooth-L1, bwd, SGD-Nesterov, EMA)",
+                        "encoders, predictor, smooth-L1, bwd, SGD-Nesterov, EMA)" + ("; target forward on a second stream" if overlap_target else ""),
             "value": round(B / dt, 1), "unit": "samples/s", "ms_per_step": round(1e3 * dt, 3), "steps": steps,
             "tflops": round(gf * B / dt / 1e3, 1), "frac_of_mfma_peak": round(gf * B / dt / 1e3 / 2500.0, 4), "final_loss": round(loss, 5)}
 
